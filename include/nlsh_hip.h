@@ -1,0 +1,152 @@
+/*
+ * nlsh_hip.h -- C ABI of the MI355X (gfx950) implementation of nlsh's query-time hot path.
+ *
+ * The reference exposes this path as duck-typed Python; the only native
+ * boundary it has is the Cython module nlsh/utils.pyx.  The entry points below are what a
+ * Python/ctypes (or cgo/JNI) binding of that path would bind; each cites the reference
+ * interface it replaces.  INTEGRATION.md shows the reference-side ctypes stub.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer marked [dev] is a DEVICE pointer
+ *     (hipMalloc / torch tensor.data_ptr()), [host] is host memory;
+ *   - the caller allocates every buffer (workspace sizes come from the *_workspace queries);
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*, NULL = default
+ *     stream); no call synchronises the device or allocates device memory;
+ *   - return 0 on success, a negative NLSH_E_* code on failure; never throws; the message of
+ *     the last failure on the calling thread is available from nlsh_last_error();
+ *   - integer outputs are bit-exact w.r.t. the oracle; fp32 outputs within the tolerance
+ *     stated in DESIGN.md.
+ */
+#ifndef NLSH_HIP_H
+#define NLSH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NLSH_ABI_VERSION 1
+
+typedef void *nlsh_stream_t; /* hipStream_t */
+
+enum {
+    NLSH_OK = 0,
+    NLSH_E_INVALID = -1,     /* bad argument (null pointer, negative size, k or P out of range) */
+    NLSH_E_UNSUPPORTED = -2, /* shape outside what the kernels are built for (see each call) */
+    NLSH_E_HIP = -3,         /* a HIP runtime call failed (message has hipGetErrorString) */
+    NLSH_E_WORKSPACE = -4    /* workspace too small */
+};
+
+enum { NLSH_ACT_SIGMOID = 0, NLSH_ACT_TANH = 1 };      /* nlsh/hashings.py:22-26 (tanh_output) */
+enum { NLSH_KEY_REF_INT16 = 0, NLSH_KEY_FULL = 1 };    /* nlsh/utils.pyx:7-15 (int16 wrap) | eval.py:49-53 */
+enum { NLSH_METRIC_L2_EPS = 0, NLSH_METRIC_COSINE = 1 }; /* nlsh/data.py:191-201 | 99-109 */
+
+#define NLSH_MAX_LAYERS 8   /* Linear layers incl. the output layer */
+#define NLSH_MAX_HASH_BITS 32
+#define NLSH_MAX_PROBES 64  /* hash_times */
+#define NLSH_MAX_K 64
+#define NLSH_MAX_DIM 1024   /* vector dimension of corpus / queries for the scan */
+#define NLSH_MAX_WIDTH 632  /* widest encoder layer (input, hidden) the LDS-resident MLP supports */
+
+int nlsh_abi_version(void);
+const char *nlsh_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Hash function forward + bit packing + multi-probe key generation.
+ * Replaces: encoder forward (encoders.py:18-21, 39-55) -> output Linear + sigmoid/tanh
+ * (nlsh/hashings.py:13-27) -> hard bits / Bernoulli samples (hashings.py:66-81) -> D2H ->
+ * binarr_to_int + set() (nlsh/utils.pyx:6-32), i.e. everything `MultivariateBernoulli.hash`
+ * does, without leaving the device.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Number of floats of the packed (MFMA-fragment-ordered) weight blob for a layer stack.
+ * dims [host] = {d_in, h_1, ..., H}, n_layers = number of Linear layers (len(dims) - 1). */
+int64_t nlsh_encoder_packed_floats(int n_layers, const int *dims);
+
+/* Pack nn.Linear-layout weights (W[l] is [dims[l+1], dims[l]] row-major, b[l] is [dims[l+1]] or
+ * NULL) into `packed` [dev].  W, b: [host] arrays of n_layers [dev] pointers.
+ * BatchNorm1d in eval mode is an affine map: fold it into W/b before packing. */
+int nlsh_encoder_pack(int n_layers, const int *dims, const float *const *W, const float *const *b,
+                      float *packed, nlsh_stream_t stream);
+
+/* x [dev] fp32 [n, d] with row stride x_stride (floats).  Outputs (all [dev], nullable unless noted):
+ *   z_out     [n, H] pre-activation of the output layer
+ *   probs_out [n, H] module output: sigmoid(z) or tanh(z)             (hashings.py:39-40 predict)
+ *   code_out  [n]    hard code, bit h of the hasher = bit (H-1-h): MSB-first (utils.pyx:12-14)
+ *   keys_out  [n, n_probes] (required) distinct keys in first-occurrence order, slot 0 = hard key;
+ *             key_mode REF_INT16: sign-extended low 16 bits; FULL: the H-bit code as int32 bits
+ *   nkeys_out [n]    (required) number of valid slots in keys_out (>= 1)
+ * Probes 1..n_probes-1 are Bernoulli(p) draws from a Philox4x32-10 stream keyed by `seed`,
+ * counter (row0 + row, probe, word): reproducible across devices and ranks.  Rows with index
+ * >= n_multi_rows are single-probe (Indexer.hash's trailing-batch rule, nlsh/indexer.py:51-53).
+ * Limits: H <= 32, n_probes <= NLSH_MAX_PROBES, every dims[l] (l < n_layers) <= NLSH_MAX_WIDTH. */
+int nlsh_encode_hash(const float *x, int64_t n, int64_t x_stride, int n_layers, const int *dims,
+                     const float *packed, int act, int key_mode, int n_probes, int64_t n_multi_rows,
+                     uint64_t seed, int64_t row0, float *z_out, float *probs_out, uint32_t *code_out,
+                     int32_t *keys_out, int32_t *nkeys_out, nlsh_stream_t stream);
+
+/* Standalone bit packing: codes [dev] int32 [B, n, H] (0/1, C-contiguous) -> keys_out [dev] int32
+ * [B, n].  Replaces binarr_to_int + the inner loop of hash_codes (nlsh/utils.pyx:6-15, 22-31);
+ * the set() of each row is formed by the host binding.  key_mode as above (FULL: eval.py:49-53). */
+int nlsh_pack_codes(const int32_t *codes, int64_t B, int n, int H, int key_mode, int32_t *keys_out,
+                    nlsh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Index build.  Replaces build_index (nlsh/indexer.py:6-24): key -> ascending row list, as CSR.
+ * ------------------------------------------------------------------------------------------- */
+size_t nlsh_build_csr_workspace(int64_t n);
+
+/* keys [dev] int32 [n] (one key per row).  Outputs [dev]: perm [n] row ids grouped by bucket
+ * (buckets in ascending signed key order, rows ascending inside a bucket), uniq_keys [n] (first
+ * *n_buckets valid), offsets [n + 1] (first *n_buckets + 1 valid), n_buckets [1]. */
+int nlsh_build_csr(const int32_t *keys, int64_t n, int32_t *perm, int32_t *uniq_keys, int32_t *offsets,
+                   int32_t *n_buckets, void *workspace, size_t workspace_bytes, nlsh_stream_t stream);
+
+/* Re-order the corpus bucket-contiguously: sorted[i, :] = corpus[perm[i], :], zero padded to
+ * dst_stride floats (dst_stride % 4 == 0, >= d).  Replaces the per-(query,key) index_select
+ * gather of nlsh/indexer.py:77-82 by a one-time permutation.  inv_norm (nullable) [n] receives
+ * 1 / max(||row||, 1e-8) (cosine).  gid (nullable) [n] receives perm[i] + id_base: the global
+ * row id the scan reports (corpus shards pass their row offset as id_base). */
+int nlsh_gather_rows(const float *corpus, int64_t src_stride, int d, const int32_t *perm, int64_t n,
+                     float *sorted, int64_t dst_stride, float *inv_norm, int32_t *gid, int32_t id_base,
+                     nlsh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Candidate scan + top-k.  Replaces the per-query loop of Indexer.query (nlsh/indexer.py:62-95):
+ * bucket lookup (:68), gather (:77-82), distance (:84-87, nlsh/data.py:99-109,191-201),
+ * cat (:88), topk + id map (:90-91), n_candidates (:71,94).
+ * ------------------------------------------------------------------------------------------- */
+size_t nlsh_scan_workspace(int64_t Q, int P, int k, int64_t max_tasks);
+
+/* corpus_sorted [dev] fp32 [N, row_stride] bucket-contiguous (nlsh_gather_rows), gid [dev] [N],
+ * uniq_keys [dev] [n_buckets] ascending, offsets [dev] [n_buckets+1], inv_norm [dev] [N] (cosine
+ * only), queries [dev] [Q, d] stride q_stride, qkeys [dev] [Q, P] with nkeys [dev] [Q] valid slots
+ * (distinct keys; unknown keys are empty buckets, never an error: indexer.py:61,68).
+ * Outputs [dev]: out_dist [Q, k] ascending, +inf padded; out_idx [Q, k] global row ids, -1 padded;
+ * out_keys (nullable) [Q, k] the 64-bit sort keys (monotone(dist) << 32 | id; ~0 padded) used by
+ * nlsh_merge_topk; out_ncand [Q] candidates per query; status [2] = {tasks needed, overflow flag}.
+ * Order is (distance asc, row id asc): deterministic refinement of torch.topk's tie order.
+ * A query's candidate list is cut into segments of `seg_rows` rows (0 = default), one wavefront
+ * each; max_tasks bounds the number of segments the workspace holds: if status[1] != 0 the
+ * results are incomplete and the call must be repeated with max_tasks >= status[0].
+ * Limits: d <= NLSH_MAX_DIM, k <= NLSH_MAX_K, P <= NLSH_MAX_PROBES. */
+int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, int d, const int32_t *gid,
+                   const int32_t *uniq_keys, const int32_t *offsets, int32_t n_buckets,
+                   const float *inv_norm, const float *queries, int64_t q_stride, int64_t Q,
+                   const int32_t *qkeys, const int32_t *nkeys, int P, int k, int metric, int seg_rows,
+                   float *out_dist, int32_t *out_idx, uint64_t *out_keys, int32_t *out_ncand,
+                   int32_t *status, void *workspace, size_t workspace_bytes, int64_t max_tasks,
+                   nlsh_stream_t stream);
+
+/* Merge G per-shard top-k lists per query (keys_in [dev] [G, Q, k], as all-gathered from
+ * nlsh_scan_topk's out_keys) into the global top-k; same comparator, so the result equals the
+ * single-GPU result.  ncand_in (nullable) [G, Q] is summed into out_ncand. */
+int nlsh_merge_topk(const uint64_t *keys_in, int G, int64_t Q, int k, const int32_t *ncand_in,
+                    float *out_dist, int32_t *out_idx, int32_t *out_ncand, nlsh_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NLSH_HIP_H */

@@ -1,0 +1,410 @@
+// encode_hash: learned hash function forward (MLP) + bit packing + multi-probe keys, one kernel.
+//
+// Replaces (reference): encoders.py:18-21,39-55 (Linear+ReLU stack) -> nlsh/hashings.py:13-27
+// (output Linear + sigmoid/tanh) -> hashings.py:66-81 (hard bits, Bernoulli samples) ->
+// .cpu().numpy() -> nlsh/utils.pyx:6-32 (binarr_to_int, set()).  Nothing leaves the device.
+//
+// gfx950 mapping
+//   * one workgroup (4 wavefronts, 256 threads) owns M = 32*RT rows; their activations never
+//     leave LDS (two ping-pong [M][S] fp32 images, 133 KB at width 256);
+//   * every Linear layer is an fp32 MFMA chain, v_mfma_f32_32x32x2_f32: exact fp32, result is
+//     bit-for-bit a k-ascending fmaf chain (guide §3 "FP32-input MFMA"), which is what the oracle
+//     computes -> z is bit-exact against oracle_mlp_forward;
+//   * weights are pre-packed in B-fragment order so that each lane fetches the B operands of four
+//     consecutive MFMA k-steps with ONE coalesced global_load_dwordx4 (1 KiB per wave-instruction;
+//     the 410 KB blob stays L2-resident); the A operands of the same four steps are ONE
+//     ds_read_b128 thanks to an even/odd de-interleaved LDS row layout (pos()); row stride
+//     S = width+4 floats with S/4 odd makes those reads conflict-free;
+//   * bias + ReLU are fused into the accumulator write-back; sigmoid/tanh, the `> 0.5` bit rule,
+//     MSB-first packing, Philox Bernoulli probes and per-row de-duplication are the epilogue.
+#include "common.h"
+
+namespace nlsh {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct LayerDesc {
+    int K, N;      // logical in/out width
+    int Kp, Np;    // padded: Kp % 8 == 0, Np % 32 == 0
+    long long w_off, b_off;  // float offsets into the packed blob
+};
+
+struct EncArgs {
+    const float *x;
+    long long n, x_stride;
+    int n_layers;
+    LayerDesc L[NLSH_MAX_LAYERS];
+    const float *packed;
+    int S;  // LDS row stride (floats)
+    int H, act, key_mode, n_probes;
+    long long n_multi_rows, row0;
+    unsigned long long seed;
+    float *z_out, *probs_out;
+    uint32_t *code_out;
+    int32_t *keys_out, *nkeys_out;
+};
+
+// position of logical column k inside an LDS row: within each group of 8, evens first then odds
+// so that lane half h reads k = 8c+h, 8c+2+h, 8c+4+h, 8c+6+h as one 16-byte word at 8c+4h.
+__device__ __forceinline__ int pos(int k) { return (k & ~7) + ((k & 1) << 2) + ((k & 7) >> 1); }
+
+__device__ __forceinline__ void philox4x32_10(unsigned long long seed, uint32_t c0, uint32_t c1, uint32_t c2,
+                                              uint32_t c3, uint32_t out[4]) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+template <int RT>
+__global__ __launch_bounds__(256) void encode_hash_kernel(EncArgs a) {
+    constexpr int M = 32 * RT;
+    extern __shared__ float4 smem4[];
+    float *smem = reinterpret_cast<float *>(smem4);
+    const int S = a.S;
+    float *in = smem;
+    float *out = smem + (size_t)M * S;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int lr = lane & 31;   // row (A) / column (B, C) inside a 32x32 tile
+    const int lh = lane >> 5;   // k parity (A, B) / row-quad select (C)
+    const long long row_base = (long long)blockIdx.x * M;
+
+    // ---- stage the input rows (zero padded to Kp, zero rows past n) in the de-interleaved layout
+    {
+        const int K0 = a.L[0].K, Kp0 = a.L[0].Kp;
+        for (int e = tid; e < M * Kp0; e += 256) {
+            int r = e / Kp0, k = e - r * Kp0;
+            long long grow = row_base + r;
+            float v = (grow < a.n && k < K0) ? a.x[grow * a.x_stride + k] : 0.0f;
+            in[r * S + pos(k)] = v;
+        }
+    }
+    __syncthreads();
+
+    for (int l = 0; l < a.n_layers; ++l) {
+        const LayerDesc L = a.L[l];
+        const int nch = L.Kp >> 3;
+        const float4 *Wp = reinterpret_cast<const float4 *>(a.packed + L.w_off);
+        const float *Bp = a.packed + L.b_off;
+        const bool last = (l + 1 == a.n_layers);
+        if (!last) {
+            const int NT = L.Np >> 5;
+            const int ncol_keep = a.L[l + 1].Kp;  // columns the next layer reads (>= N, zero padded)
+            for (int nt0 = wave; nt0 < NT; nt0 += 8) {
+                const bool has2 = (nt0 + 4) < NT;
+                const int nt1 = has2 ? nt0 + 4 : nt0;
+                f32x16 acc[RT][2];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[rt][g][i] = 0.0f;
+                const float4 *w0 = Wp + (size_t)nt0 * nch * 64 + lane;
+                const float4 *w1 = Wp + (size_t)nt1 * nch * 64 + lane;
+                const float *arow = in + (size_t)lr * S + 4 * lh;
+                float4 bn0 = w0[0], bn1 = w1[0];
+                float4 an[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) an[rt] = *reinterpret_cast<const float4 *>(arow + (size_t)rt * 32 * S);
+                for (int c = 0; c < nch; ++c) {
+                    float4 b0 = bn0, b1 = bn1;
+                    float4 av[RT];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) av[rt] = an[rt];
+                    if (c + 1 < nch) {
+                        bn0 = w0[(size_t)(c + 1) * 64];
+                        bn1 = w1[(size_t)(c + 1) * 64];
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+                            an[rt] = *reinterpret_cast<const float4 *>(arow + (size_t)rt * 32 * S + (c + 1) * 8);
+                    }
+                    const float bb0[4] = {b0.x, b0.y, b0.z, b0.w};
+                    const float bb1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) {
+                            const float aa = i == 0 ? av[rt].x : i == 1 ? av[rt].y : i == 2 ? av[rt].z : av[rt].w;
+                            acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa, bb0[i], acc[rt][0], 0, 0, 0);
+                            if (has2) acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa, bb1[i], acc[rt][1], 0, 0, 0);
+                        }
+                    }
+                }
+                // write-back: bias + ReLU (encoders.py:19-20), C/D map: col = lane&31,
+                // row = (i&3) + 8*(i>>2) + 4*(lane>>5)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    if (g == 1 && !has2) break;
+                    const int col = (g == 0 ? nt0 : nt1) * 32 + lr;
+                    if (col < ncol_keep) {
+                        const float bias = Bp[col];
+                        const int pc = pos(col);
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) {
+                                const int row = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+                                float v = acc[rt][g][i] + bias;
+                                out[(size_t)row * S + pc] = v > 0.0f ? v : 0.0f;
+                            }
+                    }
+                }
+            }
+            __syncthreads();
+            float *t = in; in = out; out = t;
+        } else {
+            // output layer: H <= 32 -> one column tile; one row tile per wavefront
+            if (wave < RT) {
+                f32x16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+                const float4 *w0 = Wp + lane;
+                const float *arow = in + (size_t)(wave * 32 + lr) * S + 4 * lh;
+                float4 bn0 = w0[0];
+                float4 an = *reinterpret_cast<const float4 *>(arow);
+                for (int c = 0; c < nch; ++c) {
+                    float4 b0 = bn0, av = an;
+                    if (c + 1 < nch) {
+                        bn0 = w0[(size_t)(c + 1) * 64];
+                        an = *reinterpret_cast<const float4 *>(arow + (c + 1) * 8);
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc, 0, 0, 0);
+                }
+                const float bias = Bp[lr];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+                    out[row * 33 + lr] = acc[i] + bias;  // z, natural column order
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue.  `out` holds z [M][33]; `in` is free.
+    const int H = a.H;
+    float *zbuf = out;
+    float *pbuf = in;  // Bernoulli probability [M][33]
+    for (int e = tid; e < M * H; e += 256) {
+        int r = e / H, h = e - r * H;
+        long long grow = row_base + r;
+        float z = zbuf[r * 33 + h];
+        float raw, p;
+        if (a.act == NLSH_ACT_SIGMOID) {  // hashings.py:26
+            raw = 1.0f / (1.0f + expf(-z));
+            p = raw;
+        } else {  // hashings.py:24 and :68-69
+            raw = tanhf(z);
+            p = raw / 2.0f + 0.5f;
+        }
+        pbuf[r * 33 + h] = p;
+        if (grow < a.n) {
+            if (a.z_out) a.z_out[grow * H + h] = z;
+            if (a.probs_out) a.probs_out[grow * H + h] = raw;
+        }
+    }
+    __syncthreads();
+    int32_t *kbuf = reinterpret_cast<int32_t *>(out);  // [M][n_probes]; z is dead now
+    const int NP = a.n_probes;
+    for (int e = tid; e < M * NP; e += 256) {
+        int r = e / NP, j = e - r * NP;
+        long long grow = row_base + r;
+        if (grow >= a.n || (j > 0 && grow >= a.n_multi_rows)) continue;
+        const unsigned long long gidx = (unsigned long long)(a.row0 + grow);
+        uint32_t code = 0;
+        uint32_t rnd[4];
+        for (int h = 0; h < H; ++h) {
+            const float p = pbuf[r * 33 + h];
+            int bit;
+            if (j == 0) {
+                bit = p > 0.5f;  // hashings.py:72: strict, on the probability
+            } else {
+                if ((h & 3) == 0) philox4x32_10(a.seed, (uint32_t)gidx, (uint32_t)(gidx >> 32), (uint32_t)j, (uint32_t)(h >> 2), rnd);
+                const float u = (float)(rnd[h & 3] >> 8) * (1.0f / 16777216.0f);
+                bit = u < p;  // Bernoulli(p) draw, hashings.py:80
+            }
+            code = (code << 1) | (uint32_t)bit;  // MSB-first, utils.pyx:12-14
+        }
+        int32_t key = a.key_mode == NLSH_KEY_REF_INT16 ? (int32_t)(int16_t)(uint16_t)(code & 0xFFFFu) : (int32_t)code;
+        kbuf[r * NP + j] = key;
+        if (j == 0 && a.code_out) a.code_out[grow] = code;
+    }
+    __syncthreads();
+    if (tid < M) {
+        const int r = tid;
+        long long grow = row_base + r;
+        if (grow < a.n) {
+            const int npr = grow < a.n_multi_rows ? NP : 1;
+            int cnt = 0;
+            for (int j = 0; j < npr; ++j) {  // set semantics (utils.pyx:26-31), first-occurrence order
+                int32_t key = kbuf[r * NP + j];
+                bool dup = false;
+                for (int t = 0; t < cnt; ++t) dup |= (kbuf[r * NP + t] == key);
+                if (!dup) kbuf[r * NP + cnt++] = key;
+            }
+            for (int t = 0; t < NP; ++t) a.keys_out[grow * NP + t] = t < cnt ? kbuf[r * NP + t] : 0;
+            a.nkeys_out[grow] = cnt;
+        }
+    }
+}
+
+// packed[w_off + ((nt*nch + c)*64 + lane)*4 + i] = W[nt*32 + (lane&31)][8c + 2i + (lane>>5)]
+__global__ void pack_weights_kernel(const float *W, const float *b, int K, int N, int Kp, int Np, float *wdst, float *bdst) {
+    const long long total = (long long)Np * Kp;
+    const int nch = Kp >> 3;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        int i = (int)(e & 3);
+        int lane = (int)((e >> 2) & 63);
+        long long rest = e >> 8;
+        int c = (int)(rest % nch);
+        int nt = (int)(rest / nch);
+        int col = nt * 32 + (lane & 31);
+        int k = 8 * c + 2 * i + (lane >> 5);
+        wdst[e] = (col < N && k < K) ? W[(size_t)col * K + k] : 0.0f;
+    }
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < Np; e += (long long)gridDim.x * blockDim.x)
+        bdst[e] = (b != nullptr && e < N) ? b[e] : 0.0f;
+}
+
+// nlsh/utils.pyx:6-15: out = (out << 1) | bit over H bits, returned as int16 (or untruncated)
+__global__ void pack_codes_kernel(const int32_t *codes, long long total, int H, int key_mode, int32_t *keys) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int32_t *p = codes + e * H;
+        uint32_t out = 0;
+        for (int h = 0; h < H; ++h) out = (out << 1) | (uint32_t)p[h];
+        keys[e] = key_mode == NLSH_KEY_REF_INT16 ? (int32_t)(int16_t)(uint16_t)(out & 0xFFFFu) : (int32_t)out;
+    }
+}
+
+static int fill_layers(int n_layers, const int *dims, LayerDesc *L, long long *total) {
+    long long off = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        L[l].K = dims[l];
+        L[l].N = dims[l + 1];
+        L[l].Kp = round_up(dims[l], 8);
+        L[l].Np = round_up(dims[l + 1], 32);
+        L[l].w_off = off;
+        off += (long long)L[l].Np * L[l].Kp;
+        L[l].b_off = off;
+        off += L[l].Np;
+    }
+    *total = off;
+    return 0;
+}
+
+static int check_dims(int n_layers, const int *dims) {
+    NLSH_REQUIRE(dims != nullptr && n_layers >= 1 && n_layers <= NLSH_MAX_LAYERS, NLSH_E_INVALID,
+                 "encoder: n_layers=%d out of range [1,%d]", n_layers, NLSH_MAX_LAYERS);
+    for (int l = 0; l <= n_layers; ++l) NLSH_REQUIRE(dims[l] >= 1, NLSH_E_INVALID, "encoder: dims[%d]=%d", l, dims[l]);
+    for (int l = 0; l < n_layers; ++l)
+        NLSH_REQUIRE(dims[l] <= NLSH_MAX_WIDTH, NLSH_E_UNSUPPORTED, "encoder: layer input width %d > %d (LDS-resident MLP)", dims[l], NLSH_MAX_WIDTH);
+    NLSH_REQUIRE(dims[n_layers] <= NLSH_MAX_HASH_BITS, NLSH_E_UNSUPPORTED, "encoder: hash_size %d > %d", dims[n_layers], NLSH_MAX_HASH_BITS);
+    return NLSH_OK;
+}
+
+}  // namespace nlsh
+
+using namespace nlsh;
+
+extern "C" int64_t nlsh_encoder_packed_floats(int n_layers, const int *dims) {
+    if (check_dims(n_layers, dims) != NLSH_OK) return -1;
+    LayerDesc L[NLSH_MAX_LAYERS];
+    long long total;
+    fill_layers(n_layers, dims, L, &total);
+    return total;
+}
+
+extern "C" int nlsh_encoder_pack(int n_layers, const int *dims, const float *const *W, const float *const *b,
+                                 float *packed, nlsh_stream_t stream) {
+    int rc = check_dims(n_layers, dims);
+    if (rc != NLSH_OK) return rc;
+    NLSH_REQUIRE(W != nullptr && b != nullptr && packed != nullptr, NLSH_E_INVALID, "encoder_pack: null pointer");
+    LayerDesc L[NLSH_MAX_LAYERS];
+    long long total;
+    fill_layers(n_layers, dims, L, &total);
+    hipStream_t s = (hipStream_t)stream;
+    for (int l = 0; l < n_layers; ++l) {
+        NLSH_REQUIRE(W[l] != nullptr, NLSH_E_INVALID, "encoder_pack: W[%d] is null", l);
+        long long tot = (long long)L[l].Np * L[l].Kp;
+        int grid = (int)((tot + 255) / 256);
+        if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, s, W[l], b[l], L[l].K, L[l].N, L[l].Kp, L[l].Np,
+                           packed + L[l].w_off, packed + L[l].b_off);
+        NLSH_CHECK_HIP(hipGetLastError());
+    }
+    return NLSH_OK;
+}
+
+extern "C" int nlsh_pack_codes(const int32_t *codes, int64_t B, int n, int H, int key_mode, int32_t *keys_out,
+                               nlsh_stream_t stream) {
+    NLSH_REQUIRE(B >= 0 && n >= 0 && H >= 1 && H <= NLSH_MAX_HASH_BITS, NLSH_E_INVALID, "pack_codes: B=%lld n=%d H=%d", (long long)B, n, H);
+    NLSH_REQUIRE(key_mode == NLSH_KEY_REF_INT16 || key_mode == NLSH_KEY_FULL, NLSH_E_INVALID, "pack_codes: key_mode=%d", key_mode);
+    const long long total = (long long)B * n;
+    if (total == 0) return NLSH_OK;
+    NLSH_REQUIRE(codes && keys_out, NLSH_E_INVALID, "pack_codes: null pointer");
+    long long grid = (total + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(pack_codes_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, codes, total, H, key_mode, keys_out);
+    NLSH_CHECK_HIP(hipGetLastError());
+    return NLSH_OK;
+}
+
+extern "C" int nlsh_encode_hash(const float *x, int64_t n, int64_t x_stride, int n_layers, const int *dims,
+                                const float *packed, int act, int key_mode, int n_probes, int64_t n_multi_rows,
+                                uint64_t seed, int64_t row0, float *z_out, float *probs_out, uint32_t *code_out,
+                                int32_t *keys_out, int32_t *nkeys_out, nlsh_stream_t stream) {
+    int rc = check_dims(n_layers, dims);
+    if (rc != NLSH_OK) return rc;
+    NLSH_REQUIRE(n >= 0, NLSH_E_INVALID, "encode_hash: n=%lld", (long long)n);
+    if (n == 0) return NLSH_OK;
+    NLSH_REQUIRE(x && packed && keys_out && nkeys_out, NLSH_E_INVALID, "encode_hash: null pointer");
+    NLSH_REQUIRE(x_stride >= dims[0], NLSH_E_INVALID, "encode_hash: x_stride %lld < d %d", (long long)x_stride, dims[0]);
+    NLSH_REQUIRE(act == NLSH_ACT_SIGMOID || act == NLSH_ACT_TANH, NLSH_E_INVALID, "encode_hash: act=%d", act);
+    NLSH_REQUIRE(key_mode == NLSH_KEY_REF_INT16 || key_mode == NLSH_KEY_FULL, NLSH_E_INVALID, "encode_hash: key_mode=%d", key_mode);
+    // hashings.py:83: "`n` should be positive integer"
+    NLSH_REQUIRE(n_probes >= 1 && n_probes <= NLSH_MAX_PROBES, NLSH_E_INVALID, "encode_hash: n_probes=%d not in [1,%d]", n_probes, NLSH_MAX_PROBES);
+
+    EncArgs a;
+    a.x = x; a.n = n; a.x_stride = x_stride; a.n_layers = n_layers; a.packed = packed;
+    long long total;
+    fill_layers(n_layers, dims, a.L, &total);
+    int maxKp = 64;
+    for (int l = 0; l < n_layers; ++l) if (a.L[l].Kp > maxKp) maxKp = a.L[l].Kp;
+    a.S = maxKp + 4;  // S/4 odd -> conflict-free ds_read_b128 of A fragments
+    a.H = dims[n_layers]; a.act = act; a.key_mode = key_mode; a.n_probes = n_probes;
+    a.n_multi_rows = n_multi_rows; a.row0 = row0; a.seed = seed;
+    a.z_out = z_out; a.probs_out = probs_out; a.code_out = code_out; a.keys_out = keys_out; a.nkeys_out = nkeys_out;
+
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds_limit = 160 * 1024;
+    if ((size_t)2 * 64 * a.S * 4 <= lds_limit) {
+        size_t lds = (size_t)2 * 64 * a.S * 4;
+        NLSH_CHECK_HIP(hipFuncSetAttribute((const void *)encode_hash_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        long long grid = (n + 63) / 64;
+        hipLaunchKernelGGL(encode_hash_kernel<2>, dim3((unsigned)grid), dim3(256), lds, s, a);
+    } else {
+        size_t lds = (size_t)2 * 32 * a.S * 4;
+        NLSH_REQUIRE(lds <= lds_limit, NLSH_E_UNSUPPORTED, "encode_hash: width %d needs %zu B of LDS", maxKp, lds);
+        NLSH_CHECK_HIP(hipFuncSetAttribute((const void *)encode_hash_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        long long grid = (n + 31) / 32;
+        hipLaunchKernelGGL(encode_hash_kernel<1>, dim3((unsigned)grid), dim3(256), lds, s, a);
+    }
+    NLSH_CHECK_HIP(hipGetLastError());
+    return NLSH_OK;
+}

@@ -1,0 +1,419 @@
+// scan_topk: bucket lookup + candidate distance scan + top-k for a whole query batch.
+//
+// Replaces the host-driven per-query loop of Indexer.query (nlsh/indexer.py:62-95): dict lookup
+// (:68), one index_select launch per (query, key) (:77-82), one distance launch per query
+// (:84-87; nlsh/data.py:99-109, 191-201), cat (:88), topk + .tolist() with a device sync per
+// query (:90-91).
+//
+// gfx950 mapping (HBM-bound: 4*d bytes and 3*d flop per candidate, 0.75 flop/B)
+//   * the corpus is bucket-contiguous (nlsh_gather_rows), so a query's candidate list is a
+//     concatenation of <= P contiguous row ranges: streaming, not gathering;
+//   * plan kernel: thread per query; binary search of each key in uniq_keys, prefix of bucket
+//     sizes, candidates cut into segments of seg_rows -> one task per segment;
+//   * scan kernel: ONE wavefront per task, one task per wave of the grid, so the hardware
+//     workgroup dispatcher load-balances skewed buckets.  A wave walks its segment in tiles of
+//     64 candidates.  LPR lanes cover one row with 16-byte loads (a wave-instruction fetches
+//     64/LPR whole rows = 1 KiB, fully coalesced), U wave-loads are kept in flight, the
+//     (q-c+eps)^2 / dot partials are reduced across the LPR lanes with DPP adds, and lane l ends
+//     up owning exactly one candidate of the tile;
+//   * per-wave top-k: the running best-64 (distance,id) keys live sorted across the 64 lanes;
+//     a tile is filtered against the k-th key with one ballot and only survivors are inserted
+//     (ballot + popcount + one lane shift), so the steady state costs ~3 instructions per tile;
+//   * queries whose candidates span several tasks are combined by a small merge kernel with the
+//     same comparator; nlsh_merge_topk does the same across corpus shards (multi-GPU).
+#include "common.h"
+
+namespace nlsh {
+
+struct ScanArgs {
+    const float *corpus;
+    long long row_stride;
+    int d;
+    const int32_t *gid;
+    const int32_t *uniq;
+    const int32_t *offsets;
+    int nb;
+    const float *inv_norm;
+    const float *queries;
+    long long q_stride;
+    long long Q;
+    const int32_t *qkeys;
+    const int32_t *nkeys;
+    int P, k, metric, seg;
+    float *out_dist;
+    int32_t *out_idx;
+    uint64_t *out_keys;
+    int32_t *out_ncand;
+    int32_t *status;
+    // workspace
+    int32_t *pstart, *pcum, *nseg, *tbase, *task_q, *task_s;
+    uint64_t *partial;
+    long long max_tasks;
+};
+
+// ------------------------------------------------------------------------------------ plan
+__global__ __launch_bounds__(256) void plan_kernel(ScanArgs a) {
+    __shared__ int32_t wsum[4];
+    __shared__ int32_t base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long q = (long long)blockIdx.x * 256 + tid;
+    int32_t C = 0, ns = 0;
+    if (q < a.Q) {
+        int nk = a.nkeys[q];
+        nk = nk < 0 ? 0 : (nk > a.P ? a.P : nk);
+        for (int p = 0; p < a.P; ++p) {
+            int32_t st = 0, sz = 0;
+            if (p < nk) {
+                const int32_t key = a.qkeys[q * a.P + p];
+                int lo = 0, hi = a.nb;  // lower_bound in the ascending bucket keys
+                while (lo < hi) {
+                    int mid = (lo + hi) >> 1;
+                    if (a.uniq[mid] < key) lo = mid + 1; else hi = mid;
+                }
+                if (lo < a.nb && a.uniq[lo] == key) {  // unknown key = empty bucket (indexer.py:61,68)
+                    st = a.offsets[lo];
+                    sz = a.offsets[lo + 1] - st;
+                }
+            }
+            a.pstart[q * a.P + p] = st;
+            a.pcum[q * a.P + p] = C;
+            C += sz;
+        }
+        ns = (C + a.seg - 1) / a.seg;
+        a.out_ncand[q] = C;  // n_candidates, indexer.py:71,94
+        if (C == 0) {
+            for (int i = 0; i < a.k; ++i) {
+                a.out_dist[q * a.k + i] = __builtin_inff();
+                a.out_idx[q * a.k + i] = -1;
+                if (a.out_keys) a.out_keys[q * a.k + i] = KEY_NONE;
+            }
+        }
+    }
+    // block-exclusive scan of ns, one atomic per block for the global task base
+    int32_t incl = ns;
+    for (int m = 1; m < 64; m <<= 1) {
+        int32_t t = __shfl_up(incl, m);
+        if (lane >= m) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    if (tid == 0) {
+        int32_t tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        base_s = tot ? atomicAdd(&a.status[0], tot) : 0;
+    }
+    __syncthreads();
+    if (q < a.Q) {
+        const int32_t tb = base_s + woff + incl - ns;
+        a.nseg[q] = ns;
+        a.tbase[q] = tb;
+        for (int s = 0; s < ns; ++s) {
+            long long t = (long long)tb + s;
+            if (t < a.max_tasks) { a.task_q[t] = (int32_t)q; a.task_s[t] = s; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ wave helpers
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+
+// sum over aligned groups of LPR lanes; every lane of a group receives the same bits
+template <int LPR>
+__device__ __forceinline__ float group_sum(float x) {
+    x += dpp_f<0xB1>(x);                    // quad_perm [1,0,3,2]
+    x += dpp_f<0x4E>(x);                    // quad_perm [2,3,0,1]
+    x += dpp_f<0x141>(x);                   // row_half_mirror
+    x += dpp_f<0x140>(x);                   // row_mirror -> 16-lane sums
+    if (LPR >= 32) x += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));  // lane ^ 16
+    if (LPR >= 64) x += __shfl_xor(x, 32);
+    return x;
+}
+
+// best-64 list, sorted ascending across lanes; insert one wave-uniform key
+__device__ __forceinline__ void topk_insert(uint64_t &top, uint64_t c, int lane) {
+    const int posn = __popcll(__ballot(top < c));
+    const uint64_t up = __shfl_up(top, 1);
+    top = lane < posn ? top : (lane == posn ? c : up);
+}
+
+__device__ __forceinline__ void topk_offer(uint64_t &top, uint64_t &tau, uint64_t key, int k, int lane) {
+    unsigned long long m = __ballot(key < tau);
+    while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const uint64_t c = __shfl(key, src);
+        if (c < tau) {
+            topk_insert(top, c, lane);
+            tau = __shfl(top, k - 1);
+        }
+    }
+}
+
+__device__ __forceinline__ void write_final(const ScanArgs &a, long long q, uint64_t top, int lane) {
+    if (lane < a.k) {
+        const bool none = top == KEY_NONE;
+        a.out_dist[q * a.k + lane] = none ? __builtin_inff() : float_from_mono((uint32_t)(top >> 32));
+        a.out_idx[q * a.k + lane] = none ? -1 : (int32_t)(uint32_t)top;
+        if (a.out_keys) a.out_keys[q * a.k + lane] = top;
+    }
+}
+
+// ------------------------------------------------------------------------------------ scan
+// LPR lanes cover one row, VPL 16-byte words per lane (d4 = ceil(d/4) <= LPR*VPL).
+template <int LPR, int VPL, int METRIC>
+__global__ __launch_bounds__(256) void scan_kernel(ScanArgs a) {
+    constexpr int RPI = 64 / LPR;              // rows per wave-load
+    constexpr int U = (VPL == 1) ? 8 : (VPL == 2 ? 4 : 2);  // wave-loads in flight
+    const int lane = threadIdx.x & 63;
+    const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    long long ntasks = a.status[0];
+    if (ntasks > a.max_tasks) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.status[1] = 1;  // incomplete: caller must retry
+        ntasks = a.max_tasks;
+    }
+    if (t >= ntasks) return;
+
+    const long long q = __builtin_amdgcn_readfirstlane(a.task_q[t]);
+    const int s = __builtin_amdgcn_readfirstlane(a.task_s[t]);
+    const int C = __builtin_amdgcn_readfirstlane(a.out_ncand[q]);
+    const int nk = __builtin_amdgcn_readfirstlane(a.nkeys[q]);
+    const int v0 = s * a.seg;
+    const int v1 = min(C, v0 + a.seg);
+
+    // probe table, one probe per lane
+    int cum_l = 0x7FFFFFFF, st_l = 0;
+    if (lane < a.P) { cum_l = a.pcum[q * a.P + lane]; st_l = a.pstart[q * a.P + lane]; }
+    const int np = nk < a.P ? nk : a.P;
+
+    // query fragment: lane li holds columns 4*(li + v*LPR) .. +3
+    const int li = lane % LPR, sub = lane / LPR;
+    const int d = a.d;
+    float4 qv[VPL];
+    bool act[VPL];
+    {
+        const float *qp = a.queries + q * a.q_stride;
+        const float padv = METRIC == NLSH_METRIC_L2_EPS ? -1e-6f : 0.0f;  // makes (q-c)+eps == 0 on padding
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int c0 = 4 * (li + v * LPR);
+            act[v] = c0 < d;
+            qv[v].x = c0 + 0 < d ? qp[c0 + 0] : padv;
+            qv[v].y = c0 + 1 < d ? qp[c0 + 1] : padv;
+            qv[v].z = c0 + 2 < d ? qp[c0 + 2] : padv;
+            qv[v].w = c0 + 3 < d ? qp[c0 + 3] : padv;
+        }
+        if (METRIC == NLSH_METRIC_COSINE) {  // x1 / max(||x1||, eps), as cosine_similarity does
+            float ss = 0.0f;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v)
+                if (act[v]) { ss = fmaf(qv[v].x, qv[v].x, ss); ss = fmaf(qv[v].y, qv[v].y, ss); ss = fmaf(qv[v].z, qv[v].z, ss); ss = fmaf(qv[v].w, qv[v].w, ss); }
+            ss = group_sum<LPR>(ss);
+            const float nrm = fmaxf(sqrtf(ss), 1e-8f);
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) { qv[v].x /= nrm; qv[v].y /= nrm; qv[v].z /= nrm; qv[v].w /= nrm; }
+        }
+    }
+
+    const float4 *corpus4 = reinterpret_cast<const float4 *>(a.corpus);
+    const long long stride4 = a.row_stride >> 2;
+    uint64_t top = KEY_NONE, tau = KEY_NONE;
+
+    for (int tile0 = v0; tile0 < v1; tile0 += 64) {
+        const int ntile = min(64, v1 - tile0);            // wave-uniform
+        const int myc = li * RPI + sub;                   // candidate of the tile this lane owns
+        const bool valid = myc < ntile;
+        const int myv = tile0 + myc;
+        int pidx = -1;                                    // last probe whose first candidate <= myv
+        for (int p = 0; p < np; ++p) pidx += (myv >= __builtin_amdgcn_readlane(cum_l, p)) ? 1 : 0;
+        pidx = valid ? pidx : 0;
+        const int stp = __shfl(st_l, pidx), cmp = __shfl(cum_l, pidx);
+        const int prow = valid ? stp + (myv - cmp) : 0;   // row in the bucket-sorted corpus
+        const int32_t mygid = valid ? a.gid[prow] : -1;
+        float myinv = 0.0f;
+        if (METRIC == NLSH_METRIC_COSINE) myinv = valid ? a.inv_norm[prow] : 0.0f;
+        float mydist = __builtin_inff();
+
+        for (int j0 = 0; j0 * RPI < ntile; j0 += U) {
+            float4 cv[U][VPL];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + u;
+                const int row = __shfl(prow, sub * LPR + (j < LPR ? j : 0));
+                const bool ok = j * RPI + sub < ntile;
+                const float4 *rp = corpus4 + (long long)row * stride4 + li;
+#pragma unroll
+                for (int v = 0; v < VPL; ++v)
+                    cv[u][v] = (ok && act[v]) ? rp[v * LPR] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + u;
+                float sacc = 0.0f;
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) {
+                    if (METRIC == NLSH_METRIC_L2_EPS) {
+                        // F.pairwise_distance: || (x1 - x2) + eps ||  (nlsh/data.py:201)
+                        float t0 = (qv[v].x - cv[u][v].x) + 1e-6f, t1 = (qv[v].y - cv[u][v].y) + 1e-6f;
+                        float t2 = (qv[v].z - cv[u][v].z) + 1e-6f, t3 = (qv[v].w - cv[u][v].w) + 1e-6f;
+                        float part = fmaf(t3, t3, fmaf(t2, t2, fmaf(t1, t1, t0 * t0)));
+                        sacc += act[v] ? part : 0.0f;
+                    } else {
+                        float part = fmaf(qv[v].w, cv[u][v].w, fmaf(qv[v].z, cv[u][v].z, fmaf(qv[v].y, cv[u][v].y, qv[v].x * cv[u][v].x)));
+                        sacc += part;
+                    }
+                }
+                const float tot = group_sum<LPR>(sacc);
+                if (li == j) mydist = tot;
+            }
+        }
+        float dist;
+        if (METRIC == NLSH_METRIC_L2_EPS) dist = sqrtf(mydist);
+        else dist = 1.0f - mydist * myinv;                // 1 - cos (nlsh/data.py:109)
+        const uint64_t key = valid ? make_key(dist, mygid) : KEY_NONE;
+        topk_offer(top, tau, key, a.k, lane);
+    }
+
+    const int ns = __builtin_amdgcn_readfirstlane(a.nseg[q]);
+    if (ns == 1) write_final(a, q, top, lane);
+    else if (lane < a.k) a.partial[t * a.k + lane] = top;
+}
+
+// ------------------------------------------------------------------------------------ merge
+__global__ __launch_bounds__(256) void merge_segments_kernel(ScanArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= a.Q) return;
+    const int ns = __builtin_amdgcn_readfirstlane(a.nseg[q]);
+    if (ns <= 1) return;
+    const long long tb = __builtin_amdgcn_readfirstlane(a.tbase[q]);
+    uint64_t top = KEY_NONE, tau = KEY_NONE;
+    for (int s = 0; s < ns; ++s) {
+        const long long t = tb + s;
+        if (t >= a.max_tasks) break;  // overflow: status[1] already set by scan_kernel
+        const uint64_t key = lane < a.k ? a.partial[t * a.k + lane] : KEY_NONE;
+        topk_offer(top, tau, key, a.k, lane);
+    }
+    write_final(a, q, top, lane);
+}
+
+__global__ __launch_bounds__(256) void merge_shards_kernel(const uint64_t *keys_in, int G, long long Q, int k,
+                                                            const int32_t *ncand_in, float *out_dist, int32_t *out_idx,
+                                                            int32_t *out_ncand) {
+    const int lane = threadIdx.x & 63;
+    const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    uint64_t top = KEY_NONE, tau = KEY_NONE;
+    int32_t nc = 0;
+    for (int g = 0; g < G; ++g) {
+        const uint64_t key = lane < k ? keys_in[((long long)g * Q + q) * k + lane] : KEY_NONE;
+        topk_offer(top, tau, key, k, lane);
+        if (ncand_in) nc += ncand_in[(long long)g * Q + q];
+    }
+    if (lane < k) {
+        const bool none = top == KEY_NONE;
+        out_dist[q * k + lane] = none ? __builtin_inff() : float_from_mono((uint32_t)(top >> 32));
+        out_idx[q * k + lane] = none ? -1 : (int32_t)(uint32_t)top;
+    }
+    if (out_ncand && ncand_in && lane == 0) out_ncand[q] = nc;
+}
+
+static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct ScanWs {
+    size_t pstart, pcum, nseg, tbase, task_q, task_s, partial, total;
+};
+static void scan_layout(long long Q, int P, int k, long long max_tasks, ScanWs *w) {
+    size_t o = 0;
+    w->pstart = o; o += al((size_t)Q * P * 4);
+    w->pcum = o;   o += al((size_t)Q * P * 4);
+    w->nseg = o;   o += al((size_t)Q * 4);
+    w->tbase = o;  o += al((size_t)Q * 4);
+    w->task_q = o; o += al((size_t)max_tasks * 4);
+    w->task_s = o; o += al((size_t)max_tasks * 4);
+    w->partial = o; o += al((size_t)max_tasks * k * 8);
+    w->total = o;
+}
+
+template <int METRIC>
+static void launch_scan(const ScanArgs &a, int d4, unsigned grid, hipStream_t s) {
+    if (d4 <= 16) hipLaunchKernelGGL((scan_kernel<16, 1, METRIC>), dim3(grid), dim3(256), 0, s, a);
+    else if (d4 <= 32) hipLaunchKernelGGL((scan_kernel<32, 1, METRIC>), dim3(grid), dim3(256), 0, s, a);
+    else if (d4 <= 64) hipLaunchKernelGGL((scan_kernel<64, 1, METRIC>), dim3(grid), dim3(256), 0, s, a);
+    else if (d4 <= 128) hipLaunchKernelGGL((scan_kernel<64, 2, METRIC>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((scan_kernel<64, 4, METRIC>), dim3(grid), dim3(256), 0, s, a);
+}
+
+}  // namespace nlsh
+
+using namespace nlsh;
+
+extern "C" size_t nlsh_scan_workspace(int64_t Q, int P, int k, int64_t max_tasks) {
+    if (Q < 0 || P < 1 || k < 1 || max_tasks < 0) { set_error("scan_workspace: bad sizes"); return 0; }
+    ScanWs w;
+    scan_layout(Q, P, k, max_tasks, &w);
+    return w.total;
+}
+
+extern "C" int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, int d, const int32_t *gid,
+                              const int32_t *uniq_keys, const int32_t *offsets, int32_t n_buckets, const float *inv_norm,
+                              const float *queries, int64_t q_stride, int64_t Q, const int32_t *qkeys, const int32_t *nkeys,
+                              int P, int k, int metric, int seg_rows, float *out_dist, int32_t *out_idx, uint64_t *out_keys,
+                              int32_t *out_ncand, int32_t *status, void *workspace, size_t workspace_bytes, int64_t max_tasks,
+                              nlsh_stream_t stream) {
+    NLSH_REQUIRE(Q >= 0 && Q < (1ll << 31), NLSH_E_INVALID, "scan_topk: Q=%lld", (long long)Q);
+    NLSH_REQUIRE(d >= 1 && d <= NLSH_MAX_DIM, NLSH_E_UNSUPPORTED, "scan_topk: d=%d not in [1,%d]", d, NLSH_MAX_DIM);
+    NLSH_REQUIRE(k >= 1 && k <= NLSH_MAX_K, NLSH_E_UNSUPPORTED, "scan_topk: k=%d not in [1,%d]", k, NLSH_MAX_K);
+    NLSH_REQUIRE(P >= 1 && P <= NLSH_MAX_PROBES, NLSH_E_UNSUPPORTED, "scan_topk: P=%d not in [1,%d]", P, NLSH_MAX_PROBES);
+    NLSH_REQUIRE(metric == NLSH_METRIC_L2_EPS || metric == NLSH_METRIC_COSINE, NLSH_E_INVALID, "scan_topk: metric=%d", metric);
+    NLSH_REQUIRE(n_buckets >= 0 && max_tasks >= 0 && seg_rows >= 0, NLSH_E_INVALID, "scan_topk: negative size");
+    if (Q == 0) return NLSH_OK;
+    NLSH_REQUIRE(queries && qkeys && nkeys && out_dist && out_idx && out_ncand && status && workspace, NLSH_E_INVALID, "scan_topk: null pointer");
+    NLSH_REQUIRE(n_buckets == 0 || (corpus_sorted && gid && uniq_keys && offsets), NLSH_E_INVALID, "scan_topk: null index pointer");
+    NLSH_REQUIRE(metric != NLSH_METRIC_COSINE || n_buckets == 0 || inv_norm, NLSH_E_INVALID, "scan_topk: cosine needs inv_norm");
+    NLSH_REQUIRE((row_stride & 3) == 0 && row_stride >= d && ((uintptr_t)corpus_sorted & 15) == 0, NLSH_E_INVALID,
+                 "scan_topk: row_stride=%lld must be a multiple of 4 and >= d, corpus 16-byte aligned", (long long)row_stride);
+    NLSH_REQUIRE(q_stride >= d, NLSH_E_INVALID, "scan_topk: q_stride < d");
+    if (seg_rows == 0) seg_rows = 512;
+    seg_rows = (seg_rows + 63) / 64 * 64;
+    ScanWs w;
+    scan_layout(Q, P, k, max_tasks, &w);
+    NLSH_REQUIRE(workspace_bytes >= w.total, NLSH_E_WORKSPACE, "scan_topk: workspace %zu < %zu", workspace_bytes, w.total);
+
+    ScanArgs a;
+    a.corpus = corpus_sorted; a.row_stride = row_stride; a.d = d; a.gid = gid; a.uniq = uniq_keys; a.offsets = offsets;
+    a.nb = n_buckets; a.inv_norm = inv_norm; a.queries = queries; a.q_stride = q_stride; a.Q = Q; a.qkeys = qkeys;
+    a.nkeys = nkeys; a.P = P; a.k = k; a.metric = metric; a.seg = seg_rows; a.out_dist = out_dist; a.out_idx = out_idx;
+    a.out_keys = out_keys; a.out_ncand = out_ncand; a.status = status; a.max_tasks = max_tasks;
+    char *base = (char *)workspace;
+    a.pstart = (int32_t *)(base + w.pstart); a.pcum = (int32_t *)(base + w.pcum); a.nseg = (int32_t *)(base + w.nseg);
+    a.tbase = (int32_t *)(base + w.tbase); a.task_q = (int32_t *)(base + w.task_q); a.task_s = (int32_t *)(base + w.task_s);
+    a.partial = (uint64_t *)(base + w.partial);
+
+    hipStream_t s = (hipStream_t)stream;
+    NLSH_CHECK_HIP(hipMemsetAsync(status, 0, 2 * sizeof(int32_t), s));
+    hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s, a);
+    if (max_tasks > 0) {
+        const unsigned grid = (unsigned)((max_tasks + 3) / 4);
+        const int d4 = (d + 3) / 4;
+        if (metric == NLSH_METRIC_L2_EPS) launch_scan<NLSH_METRIC_L2_EPS>(a, d4, grid, s);
+        else launch_scan<NLSH_METRIC_COSINE>(a, d4, grid, s);
+        hipLaunchKernelGGL(merge_segments_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, s, a);
+    }
+    NLSH_CHECK_HIP(hipGetLastError());
+    return NLSH_OK;
+}
+
+extern "C" int nlsh_merge_topk(const uint64_t *keys_in, int G, int64_t Q, int k, const int32_t *ncand_in, float *out_dist,
+                               int32_t *out_idx, int32_t *out_ncand, nlsh_stream_t stream) {
+    NLSH_REQUIRE(G >= 1 && Q >= 0 && k >= 1 && k <= NLSH_MAX_K, NLSH_E_INVALID, "merge_topk: G=%d Q=%lld k=%d", G, (long long)Q, k);
+    if (Q == 0) return NLSH_OK;
+    NLSH_REQUIRE(keys_in && out_dist && out_idx, NLSH_E_INVALID, "merge_topk: null pointer");
+    hipLaunchKernelGGL(merge_shards_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, (hipStream_t)stream, keys_in, G, (long long)Q, k,
+                       ncand_in, out_dist, out_idx, out_ncand);
+    NLSH_CHECK_HIP(hipGetLastError());
+    return NLSH_OK;
+}

@@ -1,0 +1,98 @@
+"""ctypes binding of the C ABI in include/nlsh_hip.h (lib/libnlsh_hip.so, built for gfx950).
+
+The product path has NO fallback: if the library is missing or a call fails, an exception is
+raised (`NlshHipError`).  Nothing here imports or calls the CPU oracle.
+"""
+import ctypes
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "lib", "libnlsh_hip.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+OK, E_INVALID, E_UNSUPPORTED, E_HIP, E_WORKSPACE = 0, -1, -2, -3, -4
+ACT_SIGMOID, ACT_TANH = 0, 1
+KEY_REF_INT16, KEY_FULL = 0, 1
+METRIC_L2_EPS, METRIC_COSINE = 0, 1
+MAX_LAYERS, MAX_HASH_BITS, MAX_PROBES, MAX_K, MAX_DIM, MAX_WIDTH = 8, 32, 64, 64, 1024, 632
+
+# every symbol include/nlsh_hip.h declares (tests/test_capi_symbols.py checks the header against this)
+SYMBOLS = (
+    "nlsh_abi_version", "nlsh_last_error",
+    "nlsh_encoder_packed_floats", "nlsh_encoder_pack", "nlsh_encode_hash", "nlsh_pack_codes",
+    "nlsh_build_csr_workspace", "nlsh_build_csr", "nlsh_gather_rows",
+    "nlsh_scan_workspace", "nlsh_scan_topk", "nlsh_merge_topk",
+)
+
+
+class NlshHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"nlsh_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+vp, i32, i64, u64, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_size_t
+
+
+def build_library(force=False):
+    """Compile csrc/*.hip for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-j4"]
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean"])
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NlshHipError(E_HIP, f"{LIB_PATH} not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                  f"or `make -C {CSRC}`); there is no CPU fallback")
+    L = ctypes.CDLL(LIB_PATH)
+    L.nlsh_abi_version.restype = i32
+    L.nlsh_last_error.restype = ctypes.c_char_p
+    L.nlsh_encoder_packed_floats.restype = i64
+    L.nlsh_encoder_packed_floats.argtypes = [i32, vp]
+    L.nlsh_encoder_pack.restype = i32
+    L.nlsh_encoder_pack.argtypes = [i32, vp, vp, vp, vp, vp]
+    L.nlsh_encode_hash.restype = i32
+    L.nlsh_encode_hash.argtypes = [vp, i64, i64, i32, vp, vp, i32, i32, i32, i64, u64, i64, vp, vp, vp, vp, vp, vp]
+    L.nlsh_pack_codes.restype = i32
+    L.nlsh_pack_codes.argtypes = [vp, i64, i32, i32, i32, vp, vp]
+    L.nlsh_build_csr_workspace.restype = sz
+    L.nlsh_build_csr_workspace.argtypes = [i64]
+    L.nlsh_build_csr.restype = i32
+    L.nlsh_build_csr.argtypes = [vp, i64, vp, vp, vp, vp, vp, sz, vp]
+    L.nlsh_gather_rows.restype = i32
+    L.nlsh_gather_rows.argtypes = [vp, i64, i32, vp, i64, vp, i64, vp, vp, ctypes.c_int32, vp]
+    L.nlsh_scan_workspace.restype = sz
+    L.nlsh_scan_workspace.argtypes = [i64, i32, i32, i64]
+    L.nlsh_scan_topk.restype = i32
+    L.nlsh_scan_topk.argtypes = [vp, i64, i32, vp, vp, vp, ctypes.c_int32, vp, vp, i64, i64, vp, vp, i32, i32, i32, i32,
+                                 vp, vp, vp, vp, vp, vp, sz, i64, vp]
+    L.nlsh_merge_topk.restype = i32
+    L.nlsh_merge_topk.argtypes = [vp, i32, i64, i32, vp, vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != OK:
+        raise NlshHipError(rc, lib().nlsh_last_error().decode("utf-8", "replace"))
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor / None."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def int_array(values):
+    return (ctypes.c_int * len(values))(*[int(v) for v in values])
+
+
+def ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])

@@ -1,0 +1,293 @@
+"""`build_index` / `Indexer` with the reference's surface (nlsh/indexer.py:6-96) on gfx950.
+
+Index build: hash the corpus on the device (`encode_hash`), stable radix sort of (key, row)
+-> CSR (`perm`, `uniq_keys`, `offsets`) and a bucket-contiguous copy of the corpus.
+Query: ONE `encode_hash` launch for the whole batch (multi-probe keys stay on the device) and
+ONE `nlsh_scan_topk` call (plan -> scan -> merge kernels) instead of the reference's per-query
+Python loop with ~(P+4) launches and a device sync per query.
+
+`query()` returns the reference's `(List[List[int]], List[int])`; `query_tensors()` is the same
+computation with device-resident results (what bench.py times).  compat=True (default) keeps the
+reference quirks: int16 key wrap (F2), single-probe trailing partial batch (F6), `<k` fallback =
+last key's bucket rows (F7).  No CPU fallback exists anywhere in this module.
+"""
+from typing import Dict, List, Optional, Sequence, Set, Tuple
+
+import numpy as np
+import torch
+
+from . import _capi
+from .data import metric_of
+from .hashings import keys_to_sets
+
+HASH_BATCH = 4096  # nlsh/indexer.py:40 default batch_size
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def build_csr_device(keys: torch.Tensor):
+    """int32 keys [N] (device) -> (perm int32 [N], uniq_keys int32 [nb], offsets int32 [nb+1])."""
+    L = _capi.lib()
+    keys = keys.contiguous()
+    n = keys.shape[0]
+    dev = keys.device
+    perm = torch.empty((n,), dtype=torch.int32, device=dev)
+    uniq = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+    offs = torch.empty((n + 1,), dtype=torch.int32, device=dev)
+    nb = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ws_bytes = L.nlsh_build_csr_workspace(n)
+    if ws_bytes == 0:
+        _capi.check(_capi.E_HIP)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    _capi.check(L.nlsh_build_csr(_capi.ptr(keys), n, _capi.ptr(perm), _capi.ptr(uniq), _capi.ptr(offs), _capi.ptr(nb),
+                                 _capi.ptr(ws), ws_bytes, _stream(dev)))
+    n_buckets = int(nb.item())  # index build may synchronise; the query path never does
+    return perm, uniq[:n_buckets], offs[:n_buckets + 1]
+
+
+def build_index(indexes, cuda=True) -> Dict[int, torch.Tensor]:
+    """nlsh/indexer.py:6-24: {key: LongTensor of the rows whose key set contains it, ascending}.
+
+    cuda=True sorts the (key, row) pairs with the device radix sort; cuda=False is the host-only
+    variant the reference's own unit test uses (nlsh/tests/test_indexer.py) and needs no GPU.
+    """
+    rows, keys = [], []
+    for row, key_set in enumerate(indexes):
+        for key in key_set:
+            rows.append(row)
+            keys.append(int(key))
+    if not keys:
+        return {}
+    keys_np = np.asarray(keys, dtype=np.int64)
+    rows_t = torch.as_tensor(np.asarray(rows, dtype=np.int64))
+    if cuda:
+        if keys_np.min() < -(1 << 31) or keys_np.max() >= (1 << 32):
+            raise ValueError("bucket keys must fit 32 bits")
+        k32 = torch.as_tensor(keys_np.astype(np.uint32).view(np.int32) if keys_np.max() >= (1 << 31)
+                              else keys_np.astype(np.int32)).cuda()
+        perm, uniq, offs = build_csr_device(k32)
+        grouped = rows_t.cuda()[perm.long()]
+        sizes = torch.diff(offs).cpu().tolist()
+        # report keys as the caller passed them (first pair of each bucket)
+        first = perm[offs[:-1].long()].cpu().numpy()
+        names = keys_np[first].tolist()
+    else:
+        order = torch.sort(torch.as_tensor(keys_np), stable=True)
+        uniq, counts = torch.unique_consecutive(order.values, return_counts=True)
+        grouped = rows_t[order.indices]
+        sizes = counts.tolist()
+        names = uniq.tolist()
+    return {int(k): chunk for k, chunk in zip(names, torch.split(grouped, sizes))}
+
+
+class Indexer:
+
+    def __init__(self, hashing, candidate_vectors_gpu, distance_func, compat=True, metric: Optional[str] = None,
+                 seg_rows: int = 0, id_base: int = 0):
+        self._hashing = hashing
+        self._candidate_vectors_gpu = candidate_vectors_gpu
+        self._distance_func = distance_func
+        self.compat = compat
+        self.metric = metric or metric_of(distance_func)
+        self.seg_rows = seg_rows
+        self.id_base = int(id_base)
+        self._index2row = None
+        self._ws = None
+        self._max_tasks = None
+        self._build_index()
+
+    # ------------------------------------------------------------------ build
+    def _build_index(self):
+        corpus = self._candidate_vectors_gpu
+        if corpus.device.type != "cuda":
+            raise _capi.NlshHipError(_capi.E_INVALID, "Indexer needs a device-resident corpus; there is no CPU path")
+        L = _capi.lib()
+        N, d = corpus.shape
+        if corpus.dtype != torch.float32 or corpus.stride(1) != 1:
+            corpus = corpus.float().contiguous()
+        keys, _ = self._hashing.hash_device(corpus, n=1)           # indexer.py:36-38: hash_times=1
+        self.corpus_keys = keys.view(-1)
+        self.perm, self.uniq_keys, self.offsets = build_csr_device(self.corpus_keys)
+        self.n_buckets = int(self.uniq_keys.shape[0])
+        self.dim = d
+        self.row_stride = (d + 3) // 4 * 4
+        dev = corpus.device
+        self.corpus_sorted = torch.empty((N, self.row_stride), dtype=torch.float32, device=dev)
+        self.gid = torch.empty((N,), dtype=torch.int32, device=dev)
+        self.inv_norm = torch.empty((N,), dtype=torch.float32, device=dev) if self.metric == "cosine" else None
+        _capi.check(L.nlsh_gather_rows(_capi.ptr(corpus), corpus.stride(0) if N else d, d, _capi.ptr(self.perm), N,
+                                       _capi.ptr(self.corpus_sorted), self.row_stride, _capi.ptr(self.inv_norm),
+                                       _capi.ptr(self.gid), self.id_base, _stream(dev)))
+        self._uniq_host = self.uniq_keys.cpu().numpy()
+        self._offs_host = self.offsets.cpu().numpy().astype(np.int64)
+        self.bucket_sizes = np.diff(self._offs_host)
+
+    @property
+    def index2row(self) -> Dict[int, torch.Tensor]:
+        """Reference attribute (indexer.py:38; read by trainers/base.py:87-89): materialised lazily
+        as views of one int64 copy of `perm`."""
+        if self._index2row is None:
+            rows = self.perm.long() + self.id_base
+            names = self._uniq_host.astype(np.int64)
+            if self._hashing.key_mode == _capi.KEY_FULL:
+                names = names & 0xFFFFFFFF
+            self._index2row = {int(k): v for k, v in zip(names.tolist(), torch.split(rows, self.bucket_sizes.tolist()))}
+        return self._index2row
+
+    def bucket_stats(self):
+        s = self.bucket_sizes
+        if len(s) == 0:
+            return {"n_indexes": 0, "mean": 0.0, "median": 0.0, "max": 0, "std_index_rows": 0.0}
+        return {"n_indexes": int(len(s)), "mean": float(s.mean()), "median": float(np.median(s)), "max": int(s.max()),
+                "std_index_rows": float(s.std())}
+
+    # ------------------------------------------------------------------ hashing
+    def _n_multi_rows(self, n, batch_size=HASH_BATCH):
+        # indexer.py:43-53: only full batches get hash_times; the trailing partial batch is n=1 (F6)
+        return (n // batch_size) * batch_size if self.compat else n
+
+    def hash_device(self, query_vectors, batch_size=HASH_BATCH, hash_times=1, seed=None):
+        return self._hashing.hash_device(query_vectors, n=hash_times,
+                                         n_multi_rows=self._n_multi_rows(query_vectors.shape[0], batch_size), seed=seed)
+
+    def hash(self, query_vectors, batch_size=HASH_BATCH, hash_times=1) -> List[Set[int]]:
+        keys, nkeys = self.hash_device(query_vectors, batch_size, hash_times)
+        return keys_to_sets(keys, nkeys, self._hashing.key_mode)
+
+    # ------------------------------------------------------------------ query
+    def _estimate_tasks(self, Q, P, seg):
+        s = self.bucket_sizes.astype(np.float64)
+        n = max(float(s.sum()), 1.0)
+        biased = float((s * s).sum() / n) if len(s) else 0.0          # expected size of the bucket a point lands in
+        est = Q * (1.0 + min(P, 4) * biased / seg)
+        return int(min(max(1.5 * est + 1024, Q + 1024), 2 ** 31 - 8))
+
+    def scan_tensors(self, query_vectors, keys, nkeys, k=10, want_keys=False, check=True):
+        """Scan stage on a device key table -> (dist [Q,k], idx [Q,k], ncand [Q], keys64 | None)."""
+        if self.metric not in ("l2", "cosine"):
+            raise NotImplementedError("fused scan needs metric 'l2' or 'cosine' (use SIFT.distance / Glove.distance)")
+        L = _capi.lib()
+        q = query_vectors
+        if q.device.type != "cuda":
+            raise _capi.NlshHipError(_capi.E_INVALID, "queries must be device-resident; there is no CPU path")
+        if q.dtype != torch.float32 or q.stride(1) != 1:
+            q = q.float().contiguous()
+        Q, d = q.shape
+        if d != self.dim:
+            raise ValueError(f"query dim {d} != corpus dim {self.dim}")
+        dev = q.device
+        keys = keys.contiguous()
+        nkeys = nkeys.contiguous()
+        P = keys.shape[1]
+        seg = self.seg_rows or 512
+        out_dist = torch.empty((Q, k), dtype=torch.float32, device=dev)
+        out_idx = torch.empty((Q, k), dtype=torch.int32, device=dev)
+        out_keys = torch.empty((Q, k), dtype=torch.int64, device=dev) if want_keys else None
+        ncand = torch.empty((Q,), dtype=torch.int32, device=dev)
+        status = torch.empty((2,), dtype=torch.int32, device=dev)
+        metric = _capi.METRIC_L2_EPS if self.metric == "l2" else _capi.METRIC_COSINE
+        if self._max_tasks is None:
+            self._max_tasks = self._estimate_tasks(Q, P, seg)
+        while True:
+            max_tasks = self._max_tasks
+            ws_bytes = L.nlsh_scan_workspace(Q, P, k, max_tasks)
+            if self._ws is None or self._ws.numel() < ws_bytes or self._ws.device != dev:
+                self._ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
+            _capi.check(L.nlsh_scan_topk(
+                _capi.ptr(self.corpus_sorted), self.row_stride, d, _capi.ptr(self.gid), _capi.ptr(self.uniq_keys),
+                _capi.ptr(self.offsets), self.n_buckets, _capi.ptr(self.inv_norm), _capi.ptr(q), q.stride(0) if Q else d, Q,
+                _capi.ptr(keys), _capi.ptr(nkeys), P, k, metric, seg, _capi.ptr(out_dist), _capi.ptr(out_idx),
+                _capi.ptr(out_keys), _capi.ptr(ncand), _capi.ptr(status), _capi.ptr(self._ws), self._ws.numel(), max_tasks,
+                _stream(dev)))
+            if not check or Q == 0:
+                break
+            needed, overflow = status.cpu().tolist()
+            if not overflow:
+                break
+            self._max_tasks = int(needed * 1.25) + 1024      # segment table too small: grow and repeat
+        self.last_status = status
+        return out_dist, out_idx, ncand, out_keys
+
+    def query_tensors(self, query_vectors, k=10, hash_times=10, seed=None, want_keys=False, check=True):
+        """Device-resident form of `query`: hashing + scan, nothing copied to the host."""
+        keys, nkeys = self.hash_device(query_vectors, hash_times=hash_times, seed=seed)
+        return self.scan_tensors(query_vectors, keys, nkeys, k=k, want_keys=want_keys, check=check)
+
+    def _rows_of_key(self, key):
+        """Ascending global row ids of one bucket (host list) or [] for an unknown key."""
+        key = int(key)
+        if self._hashing.key_mode == _capi.KEY_FULL and key >= (1 << 31):
+            key -= 1 << 32
+        i = int(np.searchsorted(self._uniq_host, key))
+        if i >= len(self._uniq_host) or int(self._uniq_host[i]) != key:
+            return []
+        lo, hi = int(self._offs_host[i]), int(self._offs_host[i + 1])
+        return (self.perm[lo:hi].long() + self.id_base).cpu().tolist()
+
+    def _to_lists(self, key_sets: Sequence[Sequence[int]], idx, ncand, k):
+        idx_h = idx.cpu().numpy()
+        nc_h = ncand.cpu().numpy()
+        results = []
+        for qi in range(len(nc_h)):
+            if nc_h[qi] >= k:
+                results.append(idx_h[qi].tolist())
+            elif self.compat:
+                # indexer.py:89-93 (F7): topk raises -> rows of the LAST key of the set iteration
+                order = list(key_sets[qi])
+                results.append(self._rows_of_key(order[-1]) if order else [])
+            else:
+                results.append([int(v) for v in idx_h[qi] if v >= 0])
+        return results, [int(c) for c in nc_h]
+
+    def query(self, query_vectors, k=10, hash_times=10) -> Tuple[List[List[int]], List[int]]:
+        if self.metric not in ("l2", "cosine"):
+            return self._query_generic(query_vectors, k, hash_times)
+        keys, nkeys = self.hash_device(query_vectors, hash_times=hash_times)
+        _, idx, ncand, _ = self.scan_tensors(query_vectors, keys, nkeys, k=k)
+        short = bool((ncand < k).any().item())
+        key_sets = keys_to_sets(keys, nkeys, self._hashing.key_mode) if (short and self.compat) else None
+        if key_sets is None:
+            key_sets = [()] * query_vectors.shape[0]
+        return self._to_lists(key_sets, idx, ncand, k)
+
+    def query_with_keys(self, query_vectors, key_lists: Sequence[Sequence[int]], k=10):
+        """Scan stage on caller-supplied key lists (each in the iteration order the caller saw):
+        parity on identical candidate sets, independent of hashing."""
+        Q = len(key_lists)
+        P = max([len(ks) for ks in key_lists] + [1])
+        tab = np.zeros((Q, P), dtype=np.int64)
+        cnt = np.zeros((Q,), dtype=np.int32)
+        for i, ks in enumerate(key_lists):
+            cnt[i] = len(ks)
+            tab[i, :len(ks)] = list(ks)
+        tab = np.where(tab >= (1 << 31), tab - (1 << 32), tab).astype(np.int32)
+        dev = query_vectors.device
+        keys = torch.as_tensor(tab).to(dev)
+        nkeys = torch.as_tensor(cnt).to(dev)
+        dist, idx, ncand, _ = self.scan_tensors(query_vectors, keys, nkeys, k=k)
+        res, nc = self._to_lists(key_lists, idx, ncand, k)
+        return res, nc, dist, idx
+
+    def _query_generic(self, query_vectors, k, hash_times):
+        """Arbitrary distance callable: the reference's gather -> callable -> topk per query
+        (indexer.py:62-95) on the CSR index, with stock device ops.  Not accelerated."""
+        key_sets = self.hash(query_vectors, hash_times=hash_times)
+        results, n_candidates = [], []
+        corpus = self._candidate_vectors_gpu
+        for qi, ks in enumerate(key_sets):
+            chunks = []
+            for key in list(ks):
+                kk = int(key) - (1 << 32) if int(key) >= (1 << 31) else int(key)
+                i = int(np.searchsorted(self._uniq_host, kk))
+                if i < len(self._uniq_host) and int(self._uniq_host[i]) == kk:
+                    chunks.append(self.perm[int(self._offs_host[i]):int(self._offs_host[i + 1])].long())
+            rows = torch.cat(chunks) if chunks else torch.zeros((0,), dtype=torch.int64, device=corpus.device)
+            n_candidates.append(int(rows.numel()))
+            if rows.numel() >= k:
+                dist = self._distance_func(query_vectors[qi], corpus[rows])
+                results.append((rows[dist.topk(k, largest=False)[1]] + self.id_base).tolist())
+            else:
+                results.append((chunks[-1] + self.id_base).tolist() if chunks and self.compat else (rows + self.id_base).tolist())
+        return results, n_candidates
