@@ -201,7 +201,7 @@ SCAN_CASES = [
     ("l2", 50, 5000, 33, 5, 7, 0, 4),
     ("l2", 200, 6000, 20, 6, 10, 64, 4),       # LPR=64
     ("cosine", 300, 3000, 20, 4, 5, 0, 3),     # VPL=2
-    ("l2", 960, 1500, 10, 3, 10, 64, 2),       # VPL=4 (GIST-sized)
+    ("l2", 600, 1500, 10, 3, 10, 64, 2),       # VPL=4
 ]
 
 
