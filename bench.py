@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Headline benchmark: queries/sec + recall@10 of the nlsh query-time hot path on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the hot path over the whole query batch (BASELINE.json configs[1]:
+SIFT1M-shaped, 1M x 128-d corpus, 10k queries, 16-bit hash, k=10, hash_times=10):
+encode_hash (MLP on fp32 MFMA + bits + multi-probe keys) -> plan -> scan_topk -> merge, all
+device-resident (inputs in HBM before the timed region, results left in HBM).  N>1: corpus rows
+sharded over the ranks, every rank answers all queries over its shard, one all-gather (RCCL) of the
+per-rank top-k + merge per step ("strong" scaling: total work fixed).
+
+Prints ONE JSON line (rank 0).  `roofline` is the scan kernel's algorithmic bytes (4*d*sum C_q,
+SURVEY.md §8(d)) over its HIP-event-measured duration; `cpu_baseline` is the CPU oracle timed on
+this box's host cores on a bounded sample of the same queries and candidate sets.
+There is no dataset or checkpoint offline: data is seeded synthetic, weights are seeded
+`nn.Linear`-default init (see config.hash).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "neural-locality-sensitive-hashing_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=int(os.environ.get("NLSH_BENCH_N", 1_000_000)))
+    ap.add_argument("--q", type=int, default=int(os.environ.get("NLSH_BENCH_Q", 10_000)))
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--hash-size", type=int, default=16)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--hash-times", type=int, default=10)
+    ap.add_argument("--seg-rows", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] WORLD_SIZE={world} but --gpus={args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from nlsh_amd import _capi, synth
+    from nlsh_amd.data import SIFT, brute_force_topk
+    from nlsh_amd.distributed import gather_and_merge, shard_range
+    from nlsh_amd.encoders import MultiLayerRelu
+    from nlsh_amd.hashings import MultivariateBernoulli
+    from nlsh_amd.indexer import Indexer
+    from nlsh_amd.metrics import calculate_recall
+    _capi.lib()  # fail loudly if the HIP library is missing
+
+    N, Q, d, H, k, P = args.n, args.q, args.dim, args.hash_size, args.k, args.hash_times
+    t_setup = time.time()
+    corpus_h, mean, std = synth.standardise(synth.sift_like(N, d, seed=synth.SEED_DATA))
+    queries_h, _, _ = synth.standardise(synth.sift_like(Q, d, seed=synth.SEED_QUERY), mean, std)
+    Ws, bs = synth.make_weights([d, 256, 256, H], seed=synth.SEED_WEIGHTS)
+    hashing = MultivariateBernoulli(MultiLayerRelu(d, [256, 256]), H, None, compat=True)
+    lin = [m for m in hashing._hasher.modules() if isinstance(m, torch.nn.Linear)]
+    with torch.no_grad():
+        for m, W, b in zip(lin, Ws, bs):
+            m.weight.copy_(torch.from_numpy(W))
+            m.bias.copy_(torch.from_numpy(b))
+    hashing.train_mode(False)
+
+    lo, hi = shard_range(N, rank, world)
+    shard = torch.from_numpy(corpus_h[lo:hi]).to(dev)
+    queries = torch.from_numpy(queries_h).to(dev)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    indexer = Indexer(hashing, shard, SIFT.distance, id_base=lo, seg_rows=args.seg_rows)
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+    stats = indexer.bucket_stats()
+
+    steps, warmup = args.steps, args.warmup
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in ev:  # instantiate the hipEvent handles
+        a.record(); b.record()
+
+    def step(i, check=False, events=None):
+        seed = 1000 + i  # identical on every rank -> identical multi-probe keys
+        dist_, idx_, nc_, k64 = indexer.query_tensors(queries, k=k, hash_times=P, seed=seed, want_keys=world > 1,
+                                                       check=check, events=events)
+        if world > 1:
+            dist_, idx_, nc_ = gather_and_merge(k64, nc_, k)
+        return dist_, idx_, nc_
+
+    step(-1, check=True)  # sizes the segment table (may retry once); untimed
+    for i in range(warmup):
+        step(-2 - i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = step(i, events=ev[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    overflow = int(indexer.last_status.cpu()[1])
+    assert overflow == 0, "segment table overflow inside the timed region"
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    scan_ms = [a.elapsed_time(b) for a, b in ev]
+    scan_avg_ms = float(np.mean(scan_ms))
+    dist_, idx_, nc_ = out
+    local_nc = indexer.query_tensors(queries, k=k, hash_times=P, seed=1000 + steps - 1)[2]
+    sum_c_local = int(local_nc.long().sum().item())
+    algo_bytes = 4.0 * d * sum_c_local
+    achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9
+    # the API-level call (reference return type: Python lists; includes D2H + F7 handling)
+    api_qps = None
+    if world == 1:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ids_api, nc_api = indexer.query(queries, k=k, hash_times=P)
+        api_qps = Q / (time.perf_counter() - t0)
+
+    result = None
+    if rank == 0:
+        gt = brute_force_topk(queries, torch.from_numpy(corpus_h).to(dev), k, "l2").cpu().numpy()
+        idx_h = idx_.cpu().numpy()
+        recall = float(np.mean(calculate_recall(list(gt), [r[r >= 0].tolist() for r in idx_h])))
+        mean_c = float(nc_.float().mean().item())
+        value = Q * steps / elapsed
+        result = {
+            "metric": "queries/sec + recall@10, SIFT1M 128-d 16-bit hash, 1/2/4/8 GPU",
+            "value": value, "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "recall_at_10": recall,
+            "config": {"workload": "configs[1]: SIFT1M-shaped (synthetic clustered integer SIFT-like, standardised), "
+                                   f"N={N} d={d} Q={Q} H={H} k={k} hash_times={P}",
+                       "hash": "seeded nn.Linear-default init 128->256->256->16 (no trained checkpoint exists offline)",
+                       "parallelism": f"corpus rows sharded x{world}, all-gather top-k" if world > 1 else "single GPU",
+                       "n_buckets": stats["n_indexes"], "bucket_mean": stats["mean"], "bucket_median": stats["median"],
+                       "bucket_max": stats["max"], "mean_candidates_per_query": mean_c,
+                       "index_build_s": build_s, "api_list_qps": api_qps},
+            "roofline": {"bound": "hbm", "kernel": "scan_kernel<32,1,L2>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms,
+                         "sum_candidates_per_launch": sum_c_local},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args, corpus_h, queries_h, Ws, bs, indexer, hashing, queries, steps)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, corpus_h, queries_h, Ws, bs, indexer, hashing, queries, steps):
+    """CPU oracle (oracle/: C + OpenMP scan, BLAS forward) on a bounded sample of the same workload:
+    same queries, same multi-probe keys (so identical candidate sets), same k."""
+    from oracle import oracle
+    k, P = args.k, args.hash_times
+    keys, nkeys = indexer.hash_device(queries, hash_times=P, seed=1000 + steps - 1)
+    kh, nh = keys.cpu().numpy().astype(np.int64), nkeys.cpu().numpy()
+    ck = indexer.corpus_keys.cpu().numpy().astype(np.int64)
+    perm, uniq, offs = oracle.build_csr(ck)
+    threads = oracle.num_threads()
+
+    def run(sample):
+        t0 = time.perf_counter()
+        z = oracle.mlp_forward_blas(queries_h[:sample], Ws, bs)
+        _, p01 = oracle.head_probs(z)
+        oracle.row_keys(p01, P, "ref_int16", seed=1000 + steps - 1, n_multi_rows=(sample // 4096) * 4096)
+        t1 = time.perf_counter()
+        oracle.query_batch(corpus_h, perm, uniq, offs, queries_h[:sample], kh[:sample], nh[:sample], k, "l2")
+        t2 = time.perf_counter()
+        return t1 - t0, t2 - t1
+
+    Q = len(queries_h)
+    probe = min(Q, 256)
+    th, ts = run(probe)
+    per_q = (th + ts) / probe
+    sample = int(min(Q, max(probe, args.cpu_seconds / max(per_q, 1e-9))))
+    th, ts = run(sample)
+    return {"value": sample / (th + ts), "unit": "queries/s", "cores": threads, "kind": "port",
+            "sample": f"first {sample} of {Q} queries, same keys/candidate sets as the GPU run; "
+                      f"hash {th:.3f}s (numpy BLAS) + scan {ts:.3f}s (C, OpenMP x{threads})",
+            "host_cpu_count": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

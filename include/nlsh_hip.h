@@ -131,6 +131,8 @@ size_t nlsh_scan_workspace(int64_t Q, int P, int k, int64_t max_tasks);
  * A query's candidate list is cut into segments of `seg_rows` rows (0 = default), one wavefront
  * each; max_tasks bounds the number of segments the workspace holds: if status[1] != 0 the
  * results are incomplete and the call must be repeated with max_tasks >= status[0].
+ * ev_scan_begin / ev_scan_end (nullable hipEvent_t): recorded on `stream` immediately before and
+ * after the scan kernel, so a caller can time the HBM-bound kernel alone (bench.py roofline).
  * Limits: d <= NLSH_MAX_DIM, k <= NLSH_MAX_K, P <= NLSH_MAX_PROBES. */
 int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, int d, const int32_t *gid,
                    const int32_t *uniq_keys, const int32_t *offsets, int32_t n_buckets,
@@ -138,7 +140,7 @@ int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, int d, const 
                    const int32_t *qkeys, const int32_t *nkeys, int P, int k, int metric, int seg_rows,
                    float *out_dist, int32_t *out_idx, uint64_t *out_keys, int32_t *out_ncand,
                    int32_t *status, void *workspace, size_t workspace_bytes, int64_t max_tasks,
-                   nlsh_stream_t stream);
+                   void *ev_scan_begin, void *ev_scan_end, nlsh_stream_t stream);
 
 /* Merge G per-shard top-k lists per query (keys_in [dev] [G, Q, k], as all-gathered from
  * nlsh_scan_topk's out_keys) into the global top-k; same comparator, so the result equals the

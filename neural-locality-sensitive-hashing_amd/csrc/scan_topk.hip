@@ -363,7 +363,7 @@ extern "C" int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, in
                               const float *queries, int64_t q_stride, int64_t Q, const int32_t *qkeys, const int32_t *nkeys,
                               int P, int k, int metric, int seg_rows, float *out_dist, int32_t *out_idx, uint64_t *out_keys,
                               int32_t *out_ncand, int32_t *status, void *workspace, size_t workspace_bytes, int64_t max_tasks,
-                              nlsh_stream_t stream) {
+                              void *ev_scan_begin, void *ev_scan_end, nlsh_stream_t stream) {
     NLSH_REQUIRE(Q >= 0 && Q < (1ll << 31), NLSH_E_INVALID, "scan_topk: Q=%lld", (long long)Q);
     NLSH_REQUIRE(d >= 1 && d <= NLSH_MAX_DIM, NLSH_E_UNSUPPORTED, "scan_topk: d=%d not in [1,%d]", d, NLSH_MAX_DIM);
     NLSH_REQUIRE(k >= 1 && k <= NLSH_MAX_K, NLSH_E_UNSUPPORTED, "scan_topk: k=%d not in [1,%d]", k, NLSH_MAX_K);
@@ -399,8 +399,10 @@ extern "C" int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, in
     if (max_tasks > 0) {
         const unsigned grid = (unsigned)((max_tasks + 3) / 4);
         const int d4 = (d + 3) / 4;
+        if (ev_scan_begin) NLSH_CHECK_HIP(hipEventRecord((hipEvent_t)ev_scan_begin, s));
         if (metric == NLSH_METRIC_L2_EPS) launch_scan<NLSH_METRIC_L2_EPS>(a, d4, grid, s);
         else launch_scan<NLSH_METRIC_COSINE>(a, d4, grid, s);
+        if (ev_scan_end) NLSH_CHECK_HIP(hipEventRecord((hipEvent_t)ev_scan_end, s));
         hipLaunchKernelGGL(merge_segments_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, s, a);
     }
     NLSH_CHECK_HIP(hipGetLastError());

@@ -164,7 +164,7 @@ class Indexer:
         est = Q * (1.0 + min(P, 4) * biased / seg)
         return int(min(max(1.5 * est + 1024, Q + 1024), 2 ** 31 - 8))
 
-    def scan_tensors(self, query_vectors, keys, nkeys, k=10, want_keys=False, check=True):
+    def scan_tensors(self, query_vectors, keys, nkeys, k=10, want_keys=False, check=True, events=None):
         """Scan stage on a device key table -> (dist [Q,k], idx [Q,k], ncand [Q], keys64 | None)."""
         if self.metric not in ("l2", "cosine"):
             raise NotImplementedError("fused scan needs metric 'l2' or 'cosine' (use SIFT.distance / Glove.distance)")
@@ -200,7 +200,7 @@ class Indexer:
                 _capi.ptr(self.offsets), self.n_buckets, _capi.ptr(self.inv_norm), _capi.ptr(q), q.stride(0) if Q else d, Q,
                 _capi.ptr(keys), _capi.ptr(nkeys), P, k, metric, seg, _capi.ptr(out_dist), _capi.ptr(out_idx),
                 _capi.ptr(out_keys), _capi.ptr(ncand), _capi.ptr(status), _capi.ptr(self._ws), self._ws.numel(), max_tasks,
-                _stream(dev)))
+                events[0].cuda_event if events else None, events[1].cuda_event if events else None, _stream(dev)))
             if not check or Q == 0:
                 break
             needed, overflow = status.cpu().tolist()
@@ -210,10 +210,11 @@ class Indexer:
         self.last_status = status
         return out_dist, out_idx, ncand, out_keys
 
-    def query_tensors(self, query_vectors, k=10, hash_times=10, seed=None, want_keys=False, check=True):
-        """Device-resident form of `query`: hashing + scan, nothing copied to the host."""
+    def query_tensors(self, query_vectors, k=10, hash_times=10, seed=None, want_keys=False, check=True, events=None):
+        """Device-resident form of `query`: hashing + scan, nothing copied to the host.
+        events = (begin, end) torch.cuda.Event pair (already recorded once) bracketing the scan kernel."""
         keys, nkeys = self.hash_device(query_vectors, hash_times=hash_times, seed=seed)
-        return self.scan_tensors(query_vectors, keys, nkeys, k=k, want_keys=want_keys, check=check)
+        return self.scan_tensors(query_vectors, keys, nkeys, k=k, want_keys=want_keys, check=check, events=events)
 
     def _rows_of_key(self, key):
         """Ascending global row ids of one bucket (host list) or [] for an unknown key."""

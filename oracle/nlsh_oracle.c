@@ -152,6 +152,16 @@ int oracle_row_keys(const float *p01, int H, int n_probes, int key_mode, uint64_
     return cnt;
 }
 
+/* All rows at once (rows >= n_multi_rows single-probe: nlsh/indexer.py:51-53). keys_out [n][n_probes]. */
+void oracle_rows_keys(const float *p01, int64_t n, int H, int n_probes, int key_mode, uint64_t seed, int64_t row0,
+                      int64_t n_multi_rows, int64_t *keys_out, int32_t *nkeys_out) {
+    for (int64_t r = 0; r < n; ++r) {
+        int npr = r < n_multi_rows ? n_probes : 1;
+        for (int j = 0; j < n_probes; ++j) keys_out[r * n_probes + j] = 0;
+        nkeys_out[r] = oracle_row_keys(p01 + (size_t)r * H, H, npr, key_mode, seed, row0 + r, keys_out + (size_t)r * n_probes);
+    }
+}
+
 /* ------------------------------------------------------------------ index build (CSR)
  * nlsh/indexer.py:6-24 with one key per row: bucket -> ascending row list.  Output: buckets in
  * ascending key order; perm = rows grouped by bucket (ascending inside); offsets[nb+1]. */

@@ -129,14 +129,9 @@ def row_keys(p01, n_probes, key_mode="ref_int16", seed=0, n_multi_rows=None, row
         n_multi_rows = n
     keys = np.zeros((n, n_probes), dtype=np.int64)
     nk = np.zeros(n, dtype=np.int32)
-    L = lib()
-    tmp = np.zeros(n_probes, dtype=np.int64)
-    for r in range(n):
-        npr = n_probes if r < n_multi_rows else 1
-        cnt = L.oracle_row_keys(_p(p01[r], c_f32p), H, npr, 0 if key_mode == "ref_int16" else 1,
-                                ctypes.c_uint64(seed), ctypes.c_int64(row0 + r), _p(tmp, c_i64p))
-        keys[r, :cnt] = tmp[:cnt]
-        nk[r] = cnt
+    lib().oracle_rows_keys(_p(p01, c_f32p), ctypes.c_int64(n), H, n_probes, 0 if key_mode == "ref_int16" else 1,
+                           ctypes.c_uint64(seed), ctypes.c_int64(row0), ctypes.c_int64(n_multi_rows),
+                           _p(keys, c_i64p), _p(nk, c_i32p))
     return keys, nk
 
 
