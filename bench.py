@@ -14,8 +14,8 @@ per-rank top-k + merge per step ("strong" scaling: total work fixed).
 Prints ONE JSON line (rank 0).  `roofline` is the scan kernel's algorithmic bytes (4*d*sum C_q,
 SURVEY.md §8(d)) over its HIP-event-measured duration; `cpu_baseline` is the CPU oracle timed on
 this box's host cores on a bounded sample of the same queries and candidate sets.
-There is no dataset or checkpoint offline: data is seeded synthetic, weights are seeded
-`nn.Linear`-default init (see config.hash).
+There is no dataset or reference checkpoint offline: data is seeded synthetic (`synth.sift_manifold`)
+and the hash is the one our minimal trainer learned on it (checkpoints/, see config.hash).
 """
 import argparse
 import json
@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--hash-times", type=int, default=10)
     ap.add_argument("--seg-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--random-init", action="store_true", help="ignore the learned-hash checkpoint")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
 
@@ -59,10 +60,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus and rank == 0:
         print(f"[bench] WORLD_SIZE={world} but --gpus={args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if os.environ.get("NLSH_BENCH_SAME_DEVICE"):  # rehearsal of the N>1 path on a one-GPU box (gloo, all ranks on cuda:0)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("NLSH_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from nlsh_amd import _capi, synth
     from nlsh_amd.data import SIFT, brute_force_topk
@@ -75,9 +82,17 @@ def main():
 
     N, Q, d, H, k, P = args.n, args.q, args.dim, args.hash_size, args.k, args.hash_times
     t_setup = time.time()
-    corpus_h, mean, std = synth.standardise(synth.sift_like(N, d, seed=synth.SEED_DATA))
-    queries_h, _, _ = synth.standardise(synth.sift_like(Q, d, seed=synth.SEED_QUERY), mean, std)
-    Ws, bs = synth.make_weights([d, 256, 256, H], seed=synth.SEED_WEIGHTS)
+    corpus_h, mean, std = synth.standardise(synth.sift_manifold(N, d, seed=synth.SEED_DATA))
+    queries_h, _, _ = synth.standardise(synth.sift_manifold(Q, d, seed=synth.SEED_QUERY), mean, std)
+    ckpt = os.path.join(ROOT, "neural-locality-sensitive-hashing_amd", "checkpoints", "sift1m_manifold_h16.npz")
+    if d == 128 and H == 16 and os.path.exists(ckpt) and not args.random_init:
+        arrs = np.load(ckpt)
+        Ws, bs = [arrs[f"W{i}"] for i in range(3)], [arrs[f"b{i}"] for i in range(3)]
+        hash_desc = ("learned: triplet loss (margin 1.0, random negatives, 5000 Adam steps, tools/train_hash.py) on this "
+                     "synthetic corpus, 128->256->256->16, checkpoints/sift1m_manifold_h16.npz")
+    else:
+        Ws, bs = synth.make_weights([d, 256, 256, H], seed=synth.SEED_WEIGHTS)
+        hash_desc = f"seeded nn.Linear-default init {d}->256->256->{H} (random-init hash)"
     hashing = MultivariateBernoulli(MultiLayerRelu(d, [256, 256]), H, None, compat=True)
     lin = [m for m in hashing._hasher.modules() if isinstance(m, torch.nn.Linear)]
     with torch.no_grad():
@@ -159,9 +174,9 @@ def main():
             "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "recall_at_10": recall,
-            "config": {"workload": "configs[1]: SIFT1M-shaped (synthetic clustered integer SIFT-like, standardised), "
-                                   f"N={N} d={d} Q={Q} H={H} k={k} hash_times={P}",
-                       "hash": "seeded nn.Linear-default init 128->256->256->16 (no trained checkpoint exists offline)",
+            "config": {"workload": "configs[1]: SIFT1M-shaped (synthetic SIFT-like integers on a 6-d latent manifold, "
+                                   f"synth.sift_manifold, standardised), N={N} d={d} Q={Q} H={H} k={k} hash_times={P}",
+                       "hash": hash_desc,
                        "parallelism": f"corpus rows sharded x{world}, all-gather top-k" if world > 1 else "single GPU",
                        "n_buckets": stats["n_indexes"], "bucket_mean": stats["mean"], "bucket_median": stats["median"],
                        "bucket_max": stats["max"], "mean_candidates_per_query": mean_c,

@@ -30,6 +30,35 @@ def sift_like(n, d=128, seed=SEED_DATA, n_clusters=1000, sigma=24.0, chunk=1 << 
     return out
 
 
+def sift_manifold(n, d=128, seed=SEED_DATA, latent_dim=6, n_clusters=32, spread=0.5, chunk=1 << 16):
+    """SIFT-like integers in [0, 218] with LOW INTRINSIC DIMENSION (a random smooth map of a
+    `latent_dim`-d Gaussian mixture), so that nearest neighbours are meaningful.
+
+    `sift_like` (isotropic 128-d noise around cluster centres) has concentrated distances: the 10-NN
+    of a point are arbitrary members of its 1000-point cluster, so recall@10 of ANY space partition is
+    ~ candidates/1000.  Real SIFT descriptors have intrinsic dimension ~10; this generator is what the
+    learned-hash bench workload uses, `sift_like` stays for the golden fixtures.
+    """
+    g = np.random.default_rng(SEED_CENTRES + 7)
+    A1 = g.standard_normal((latent_dim, 64)).astype(np.float32)
+    b1 = g.uniform(-1, 1, size=64).astype(np.float32)
+    A2 = (g.standard_normal((64, d)) / 8.0).astype(np.float32)
+    cen = g.standard_normal((n_clusters, latent_dim)).astype(np.float32)
+
+    def fmap(z):
+        return np.maximum(z @ A1 + b1, 0) @ A2
+
+    cal = fmap(cen[g.integers(0, n_clusters, 8192)] + spread * g.standard_normal((8192, latent_dim)).astype(np.float32))
+    mu, sd = np.float32(cal.mean()), np.float32(cal.std())
+    rng = np.random.default_rng(seed)
+    out = np.empty((n, d), dtype=np.float32)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        z = cen[rng.integers(0, n_clusters, size=e - s)] + np.float32(spread) * rng.standard_normal((e - s, latent_dim), dtype=np.float32)
+        out[s:e] = np.clip(np.rint(64.0 + 32.0 * (fmap(z) - mu) / sd), 0, 218)
+    return out
+
+
 def glove_like(n, d=100, seed=SEED_DATA, chunk=1 << 16):
     """N(0,1) rows with a fixed per-dimension scale in U(0.3, 1.0) (cosine workloads)."""
     scale = np.random.default_rng(SEED_CENTRES + 1).uniform(0.3, 1.0, size=d).astype(np.float32)

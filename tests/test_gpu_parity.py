@@ -310,3 +310,30 @@ def test_sift_small_end_to_end_g7():
     # multi-probe query (hash_times=10): Q=100 < 4096 -> every query single-probe in compat mode (F6)
     ids10, nc10 = indexer.query(dev(queries), k=10, hash_times=10)
     assert nc10 == nc
+
+
+# ----------------------------------------------------------------------------- (e) shards: merge == single GPU
+@pytest.mark.parametrize("G", [2, 3, 8])
+def test_sharded_scan_plus_merge_equals_single_index(G):
+    from nlsh_amd.data import SIFT
+    from nlsh_amd.distributed import merge_topk_device, shard_range
+    from nlsh_amd.indexer import Indexer
+    N, Q, d, H, k, P = 30000, 200, 128, 7, 10, 6
+    corpus, _, _ = synth.standardise(synth.sift_like(N, d, seed=8))
+    queries, _, _ = synth.standardise(synth.sift_like(Q, d, seed=9))
+    corpus[100:140] = corpus[20000:20040]                          # exact ties across shards
+    Ws, bs = synth.make_weights([d, 64, H], seed=8)
+    hashing = make_hashing(d, (64,), H, Ws, bs)
+    qd = dev(queries)
+    single = Indexer(hashing, dev(corpus), SIFT.distance)
+    d1, i1, n1, _ = single.query_tensors(qd, k=k, hash_times=P, seed=77)
+    keys_all, nc_all = [], []
+    for r in range(G):
+        lo, hi = shard_range(N, r, G)
+        sh = Indexer(hashing, dev(corpus[lo:hi]), SIFT.distance, id_base=lo)
+        _, _, nc, k64 = sh.query_tensors(qd, k=k, hash_times=P, seed=77, want_keys=True)
+        keys_all.append(k64); nc_all.append(nc)
+    dm, im, nm = merge_topk_device(torch.stack(keys_all), torch.stack(nc_all), k)
+    assert torch.equal(nm, n1)                                      # candidate counts add up exactly
+    assert torch.equal(im, i1)                                      # same comparator -> identical ids
+    assert torch.equal(dm, d1)                                      # and bit-identical distances
