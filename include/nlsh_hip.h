@@ -42,6 +42,8 @@ enum {
 enum { NLSH_ACT_SIGMOID = 0, NLSH_ACT_TANH = 1 };      /* nlsh/hashings.py:22-26 (tanh_output) */
 enum { NLSH_KEY_REF_INT16 = 0, NLSH_KEY_FULL = 1 };    /* nlsh/utils.pyx:7-15 (int16 wrap) | eval.py:49-53 */
 enum { NLSH_METRIC_L2_EPS = 0, NLSH_METRIC_COSINE = 1 }; /* nlsh/data.py:191-201 | 99-109 */
+/* schedules of nlsh_scan_topk (identical results): one wave per (query, segment) | per (bucket segment, <=8 queries) */
+enum { NLSH_SCAN_QUERY_MAJOR = 0, NLSH_SCAN_BUCKET_MAJOR = 1 };
 
 #define NLSH_MAX_LAYERS 8   /* Linear layers incl. the output layer */
 #define NLSH_MAX_HASH_BITS 32
@@ -118,7 +120,7 @@ int nlsh_gather_rows(const float *corpus, int64_t src_stride, int d, const int32
  * bucket lookup (:68), gather (:77-82), distance (:84-87, nlsh/data.py:99-109,191-201),
  * cat (:88), topk + id map (:90-91), n_candidates (:71,94).
  * ------------------------------------------------------------------------------------------- */
-size_t nlsh_scan_workspace(int64_t Q, int P, int k, int64_t max_tasks);
+size_t nlsh_scan_workspace(int64_t Q, int P, int k, int64_t max_tasks, int64_t n_buckets);
 
 /* corpus_sorted [dev] fp32 [N, row_stride] bucket-contiguous (nlsh_gather_rows), gid [dev] [N],
  * uniq_keys [dev] [n_buckets] ascending, offsets [dev] [n_buckets+1], inv_norm [dev] [N] (cosine
@@ -137,7 +139,7 @@ size_t nlsh_scan_workspace(int64_t Q, int P, int k, int64_t max_tasks);
 int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, int d, const int32_t *gid,
                    const int32_t *uniq_keys, const int32_t *offsets, int32_t n_buckets,
                    const float *inv_norm, const float *queries, int64_t q_stride, int64_t Q,
-                   const int32_t *qkeys, const int32_t *nkeys, int P, int k, int metric, int seg_rows,
+                   const int32_t *qkeys, const int32_t *nkeys, int P, int k, int metric, int algo, int seg_rows,
                    float *out_dist, int32_t *out_idx, uint64_t *out_keys, int32_t *out_ncand,
                    int32_t *status, void *workspace, size_t workspace_bytes, int64_t max_tasks,
                    void *ev_scan_begin, void *ev_scan_end, nlsh_stream_t stream);

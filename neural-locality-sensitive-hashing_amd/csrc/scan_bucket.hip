@@ -1,0 +1,319 @@
+// Bucket-major candidate scan (algo NLSH_SCAN_BUCKET_MAJOR of nlsh_scan_topk).
+//
+// Same contract and arithmetic as the query-major kernel (scan_topk.hip; reference
+// nlsh/indexer.py:62-95), different schedule: when many queries of a batch probe the same buckets
+// (SIFT1M-shaped run: 10k queries x 10 probes over 5.8k buckets -> every corpus row is a candidate
+// of ~24 queries) the query-major kernel re-reads each row once per query and sits on the HBM
+// roofline.  Here the (query, probe) pairs are inverted into per-bucket query lists on the device
+// and ONE wavefront scores a row tile against a GROUP of up to QB=8 queries held in registers, so a
+// row is fetched ceil(m_b/QB) times instead of m_b times; the kernel moves from HBM-bound towards
+// VALU-bound (19 VALU per row-pair and query).
+//
+// Per batch, all on the caller's stream, no host round trip:
+//   bplan    thread/(query,probe): binary search key -> bucket; count pairs per bucket; C_q
+//   bscan    thread/bucket: block scan + one atomic per block -> disjoint pair/task ranges;
+//            task = (group of <= QB pairs, segment of <= seg_rows rows)
+//   bscatter thread/(query,probe): claim a slot in the bucket's query list
+//   bscan2   wave/task: stream the segment once, keep QB best-64 lists, write partial top-k
+//   bmerge   wave/query: merge the partial lists of its (probe, segment) pairs -> final top-k
+// Results do not depend on slot/task order: every list is merged with the (distance, id) comparator.
+#include "scan_common.h"
+
+namespace nlsh {
+
+struct BArgs {
+    const float *corpus;
+    long long row_stride;
+    int d;
+    const int32_t *gid;
+    const int32_t *uniq;
+    const int32_t *offsets;
+    int nb;
+    const float *inv_norm;
+    const float *queries;
+    long long q_stride;
+    long long Q;
+    const int32_t *qkeys;
+    const int32_t *nkeys;
+    int P, k, seg, QB;
+    float *out_dist;
+    int32_t *out_idx;
+    uint64_t *out_keys;
+    int32_t *out_ncand;
+    int32_t *status;
+    int32_t *pbkt, *pairpos, *inv_q, *bcount, *pairoff, *taskoff, *counters;
+    int4 *task;
+    uint64_t *partial;
+    long long max_tasks;
+};
+
+__global__ __launch_bounds__(256) void bplan_kernel(BArgs a) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.Q * a.P) return;
+    const long long q = idx / a.P;
+    const int p = (int)(idx - q * a.P);
+    int nk = a.nkeys[q];
+    nk = nk < 0 ? 0 : (nk > a.P ? a.P : nk);
+    int b = -1;
+    if (p < nk) {
+        const int32_t key = a.qkeys[idx];
+        int lo = 0, hi = a.nb;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (a.uniq[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        if (lo < a.nb && a.uniq[lo] == key) {  // unknown key = empty bucket (indexer.py:61,68)
+            const int sz = a.offsets[lo + 1] - a.offsets[lo];
+            if (sz > 0) {
+                b = lo;
+                atomicAdd(&a.bcount[lo], 1);
+                atomicAdd(&a.out_ncand[q], sz);  // n_candidates (indexer.py:71,94)
+            }
+        }
+    }
+    a.pbkt[idx] = b;
+}
+
+__device__ __forceinline__ int block_excl_scan(int v, int *wsum, int *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+    for (int m = 1; m < 64; m <<= 1) {
+        int t = __shfl_up(incl, m);
+        if (lane >= m) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    return woff + incl - v;
+}
+
+__global__ __launch_bounds__(256) void bscan_kernel(BArgs a) {
+    __shared__ int wsum[4];
+    __shared__ int base_m, base_t;
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    int m = 0, s = 0, ns = 0, nt = 0;
+    if (b < a.nb) {
+        m = a.bcount[b];
+        s = a.offsets[b + 1] - a.offsets[b];
+        ns = (s + a.seg - 1) / a.seg;
+        nt = ((m + a.QB - 1) / a.QB) * ns;
+    }
+    int tot_m, tot_t;
+    const int ex_m = block_excl_scan(m, wsum, &tot_m);
+    const int ex_t = block_excl_scan(nt, wsum, &tot_t);
+    if (threadIdx.x == 0) {
+        base_m = tot_m ? atomicAdd(&a.counters[0], tot_m) : 0;
+        base_t = tot_t ? atomicAdd(&a.status[0], tot_t) : 0;
+    }
+    __syncthreads();
+    if (b < a.nb) {
+        const int po = base_m + ex_m, to = base_t + ex_t;
+        a.pairoff[b] = po;
+        a.taskoff[b] = to;
+        const int row0 = a.offsets[b];
+        for (int t = 0; t < nt; ++t) {
+            const long long tt = (long long)to + t;
+            if (tt >= a.max_tasks) break;
+            const int gi = t / ns, si = t - gi * ns;
+            a.task[tt] = make_int4(po + gi * a.QB, min(a.QB, m - gi * a.QB), row0 + si * a.seg, min(a.seg, s - si * a.seg));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bscatter_kernel(BArgs a) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.Q * a.P) return;
+    const int b = a.pbkt[idx];
+    if (b < 0) return;
+    const int pos = a.pairoff[b] + atomicSub(&a.bcount[b], 1) - 1;
+    a.inv_q[pos] = (int32_t)(idx / a.P);
+    a.pairpos[idx] = pos;
+}
+
+// One task: stream `nrows` rows starting at row0 once, score them against the nq <= QB queries of
+// the group.  FULL (nq == QB, the common case in hot buckets) compiles without per-query branches.
+template <int LPR, int VPL, int METRIC, int QB, bool FULL>
+__device__ __forceinline__ void bscan2_task(const BArgs &a, long long t, int pair0, int nq, int row0, int nrows, int lane) {
+    constexpr int RPI = 64 / LPR;
+    constexpr int U = (VPL == 1) ? 8 : (VPL == 2 ? 4 : 2);
+    const int li = lane % LPR, sub = lane / LPR;
+    float4 qv[QB][VPL];
+    bool act[VPL];
+    uint64_t top[QB], tau[QB];
+#pragma unroll
+    for (int jq = 0; jq < QB; ++jq) {
+        top[jq] = KEY_NONE;
+        tau[jq] = KEY_NONE;
+        const int qi = __builtin_amdgcn_readfirstlane(a.inv_q[pair0 + ((FULL || jq < nq) ? jq : 0)]);
+        load_query<LPR, VPL, METRIC>(a.queries + (long long)qi * a.q_stride, a.d, li, qv[jq], act);
+    }
+
+    const float4 *corpus4 = reinterpret_cast<const float4 *>(a.corpus);
+    const long long stride4 = a.row_stride >> 2;
+    for (int tile0 = 0; tile0 < nrows; tile0 += 64) {
+        const int ntile = min(64, nrows - tile0);
+        const int myc = li * RPI + sub;
+        const bool valid = myc < ntile;
+        const int prow = row0 + tile0 + (valid ? myc : 0);
+        const int32_t mygid = valid ? a.gid[prow] : -1;
+        float myinv = 0.0f;
+        if (METRIC == NLSH_METRIC_COSINE) myinv = valid ? a.inv_norm[prow] : 0.0f;
+        float mydist[QB];
+#pragma unroll
+        for (int jq = 0; jq < QB; ++jq) mydist[jq] = __builtin_inff();
+        const float4 *tile4 = corpus4 + (long long)(row0 + tile0) * stride4 + li;
+        for (int j0 = 0; j0 * RPI < ntile; j0 += U) {
+            float4 cv[U][VPL];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = (j0 + u) * RPI + sub;  // row of the tile this lane group covers
+                const bool ok = r < ntile;
+                const float4 *rp = tile4 + (long long)r * stride4;
+#pragma unroll
+                for (int v = 0; v < VPL; ++v)
+                    cv[u][v] = (ok && act[v]) ? rp[v * LPR] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool mine = li == j0 + u;
+#pragma unroll
+                for (int jq = 0; jq < QB; ++jq) {
+                    if (FULL || jq < nq) {
+                        const float tot = group_sum<LPR>(row_partial<VPL, METRIC>(qv[jq], act, cv[u]));
+                        mydist[jq] = mine ? tot : mydist[jq];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int jq = 0; jq < QB; ++jq) {
+            if (FULL || jq < nq) {
+                const float dist = finish_distance<METRIC>(mydist[jq], myinv);
+                const uint64_t key = valid ? make_key(dist, mygid) : KEY_NONE;
+                topk_offer(top[jq], tau[jq], key, a.k, lane);
+            }
+        }
+    }
+#pragma unroll
+    for (int jq = 0; jq < QB; ++jq)
+        if ((FULL || jq < nq) && lane < a.k) a.partial[((long long)t * QB + jq) * a.k + lane] = top[jq];
+}
+
+template <int LPR, int VPL, int METRIC, int QB>
+__global__ __launch_bounds__(256) void bscan2_kernel(BArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    long long ntasks = a.status[0];
+    if (ntasks > a.max_tasks) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.status[1] = 1;  // incomplete: caller must retry
+        ntasks = a.max_tasks;
+    }
+    if (t >= ntasks) return;
+    const int4 desc = a.task[t];
+    const int pair0 = __builtin_amdgcn_readfirstlane(desc.x);
+    const int nq = __builtin_amdgcn_readfirstlane(desc.y);
+    const int row0 = __builtin_amdgcn_readfirstlane(desc.z);
+    const int nrows = __builtin_amdgcn_readfirstlane(desc.w);
+    if (nq == QB) bscan2_task<LPR, VPL, METRIC, QB, true>(a, t, pair0, nq, row0, nrows, lane);
+    else bscan2_task<LPR, VPL, METRIC, QB, false>(a, t, pair0, nq, row0, nrows, lane);
+}
+
+__global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= a.Q) return;
+    int nk = __builtin_amdgcn_readfirstlane(a.nkeys[q]);
+    nk = nk < 0 ? 0 : (nk > a.P ? a.P : nk);
+    uint64_t top = KEY_NONE, tau = KEY_NONE;
+    for (int p = 0; p < nk; ++p) {
+        const int b = __builtin_amdgcn_readfirstlane(a.pbkt[q * a.P + p]);
+        if (b < 0) continue;
+        const int rel = __builtin_amdgcn_readfirstlane(a.pairpos[q * a.P + p]) - __builtin_amdgcn_readfirstlane(a.pairoff[b]);
+        const int gi = rel / a.QB, j = rel - gi * a.QB;
+        const int s = __builtin_amdgcn_readfirstlane(a.offsets[b + 1]) - __builtin_amdgcn_readfirstlane(a.offsets[b]);
+        const int ns = (s + a.seg - 1) / a.seg;
+        const long long t0 = (long long)__builtin_amdgcn_readfirstlane(a.taskoff[b]) + (long long)gi * ns;
+        for (int si = 0; si < ns; ++si) {
+            const long long t = t0 + si;
+            if (t >= a.max_tasks) break;  // overflow: status[1] set by bscan2
+            const uint64_t key = lane < a.k ? a.partial[(t * a.QB + j) * a.k + lane] : KEY_NONE;
+            topk_offer(top, tau, key, a.k, lane);
+        }
+    }
+    store_topk(a.out_dist, a.out_idx, a.out_keys, q, a.k, top, lane);
+}
+
+struct BWs {
+    size_t pbkt, pairpos, inv_q, bcount, pairoff, taskoff, counters, task, partial, total;
+};
+static void blayout(long long Q, int P, int k, long long max_tasks, long long nb, BWs *w) {
+    size_t o = 0;
+    const size_t qp = (size_t)Q * P * 4, nb4 = (size_t)(nb > 0 ? nb : 1) * 4;
+    w->pbkt = o;     o += ws_align(qp);
+    w->pairpos = o;  o += ws_align(qp);
+    w->inv_q = o;    o += ws_align(qp);
+    w->bcount = o;   o += ws_align(nb4);
+    w->pairoff = o;  o += ws_align(nb4);
+    w->taskoff = o;  o += ws_align(nb4);
+    w->counters = o; o += ws_align(16);
+    w->task = o;     o += ws_align((size_t)max_tasks * sizeof(int4));
+    w->partial = o;  o += ws_align((size_t)max_tasks * 8 * k * 8);
+    w->total = o;
+}
+
+size_t bucket_scan_workspace(long long Q, int P, int k, long long max_tasks, long long n_buckets) {
+    BWs w;
+    blayout(Q, P, k, max_tasks, n_buckets, &w);
+    return w.total;
+}
+
+template <int METRIC>
+static void launch_bscan2(const BArgs &a, int d4, unsigned grid, hipStream_t s) {
+    if (d4 <= 16) hipLaunchKernelGGL((bscan2_kernel<16, 1, METRIC, 8>), dim3(grid), dim3(256), 0, s, a);
+    else if (d4 <= 32) hipLaunchKernelGGL((bscan2_kernel<32, 1, METRIC, 8>), dim3(grid), dim3(256), 0, s, a);
+    else if (d4 <= 64) hipLaunchKernelGGL((bscan2_kernel<64, 1, METRIC, 8>), dim3(grid), dim3(256), 0, s, a);
+    else if (d4 <= 128) hipLaunchKernelGGL((bscan2_kernel<64, 2, METRIC, 4>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((bscan2_kernel<64, 4, METRIC, 2>), dim3(grid), dim3(256), 0, s, a);
+}
+
+int bucket_scan_run(const BucketScanCall &c) {
+    BWs w;
+    blayout(c.Q, c.P, c.k, c.max_tasks, c.nb, &w);
+    NLSH_REQUIRE(c.workspace_bytes >= w.total, NLSH_E_WORKSPACE, "scan_topk(bucket-major): workspace %zu < %zu", c.workspace_bytes, w.total);
+    const int d4 = (c.d + 3) / 4;
+    BArgs a;
+    a.corpus = c.corpus; a.row_stride = c.row_stride; a.d = c.d; a.gid = c.gid; a.uniq = c.uniq; a.offsets = c.offsets; a.nb = c.nb;
+    a.inv_norm = c.inv_norm; a.queries = c.queries; a.q_stride = c.q_stride; a.Q = c.Q; a.qkeys = c.qkeys; a.nkeys = c.nkeys;
+    a.P = c.P; a.k = c.k; a.seg = c.seg; a.QB = d4 <= 64 ? 8 : (d4 <= 128 ? 4 : 2);
+    a.out_dist = c.out_dist; a.out_idx = c.out_idx; a.out_keys = c.out_keys; a.out_ncand = c.out_ncand; a.status = c.status;
+    char *base = (char *)c.workspace;
+    a.pbkt = (int32_t *)(base + w.pbkt); a.pairpos = (int32_t *)(base + w.pairpos); a.inv_q = (int32_t *)(base + w.inv_q);
+    a.bcount = (int32_t *)(base + w.bcount); a.pairoff = (int32_t *)(base + w.pairoff); a.taskoff = (int32_t *)(base + w.taskoff);
+    a.counters = (int32_t *)(base + w.counters); a.task = (int4 *)(base + w.task); a.partial = (uint64_t *)(base + w.partial);
+    a.max_tasks = c.max_tasks;
+
+    hipStream_t s = c.stream;
+    NLSH_CHECK_HIP(hipMemsetAsync(c.status, 0, 2 * sizeof(int32_t), s));
+    NLSH_CHECK_HIP(hipMemsetAsync(a.counters, 0, 16, s));
+    NLSH_CHECK_HIP(hipMemsetAsync(a.bcount, 0, (size_t)(c.nb > 0 ? c.nb : 1) * 4, s));
+    NLSH_CHECK_HIP(hipMemsetAsync(c.out_ncand, 0, (size_t)c.Q * 4, s));
+    const unsigned gp = (unsigned)((c.Q * c.P + 255) / 256);
+    hipLaunchKernelGGL(bplan_kernel, dim3(gp), dim3(256), 0, s, a);
+    if (c.nb > 0) hipLaunchKernelGGL(bscan_kernel, dim3((unsigned)((c.nb + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bscatter_kernel, dim3(gp), dim3(256), 0, s, a);
+    if (c.max_tasks > 0) {
+        const unsigned grid = (unsigned)((c.max_tasks + 3) / 4);
+        if (c.ev_begin) NLSH_CHECK_HIP(hipEventRecord((hipEvent_t)c.ev_begin, s));
+        if (c.metric == NLSH_METRIC_L2_EPS) launch_bscan2<NLSH_METRIC_L2_EPS>(a, d4, grid, s);
+        else launch_bscan2<NLSH_METRIC_COSINE>(a, d4, grid, s);
+        if (c.ev_end) NLSH_CHECK_HIP(hipEventRecord((hipEvent_t)c.ev_end, s));
+    }
+    hipLaunchKernelGGL(bmerge_kernel, dim3((unsigned)((c.Q + 3) / 4)), dim3(256), 0, s, a);
+    NLSH_CHECK_HIP(hipGetLastError());
+    return NLSH_OK;
+}
+
+}  // namespace nlsh

@@ -1,0 +1,133 @@
+// Wave-level building blocks shared by the query-major and bucket-major scan kernels.
+#pragma once
+#include "common.h"
+
+namespace nlsh {
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+
+// sum over aligned groups of LPR lanes; every lane of a group receives the same bits
+template <int LPR>
+__device__ __forceinline__ float group_sum(float x) {
+    x += dpp_f<0xB1>(x);                    // quad_perm [1,0,3,2]
+    x += dpp_f<0x4E>(x);                    // quad_perm [2,3,0,1]
+    x += dpp_f<0x141>(x);                   // row_half_mirror
+    x += dpp_f<0x140>(x);                   // row_mirror -> 16-lane sums
+    // gfx950 v_permlane16_swap / v_permlane32_swap exchange 16-lane rows / 32-lane halves between
+    // TWO registers (semantics probed on hardware: tools/probe_permlane.hip): with a = b = x,
+    // a' = {x0,x0,x2,x2}, b' = {x1,x1,x3,x3}, so a' + b' is the cross-row sum in every lane with no
+    // LDS round trip.  Written as asm: through the builtin hipcc (ROCm 7.2) folded the second result
+    // into the first when both inputs carry the same value and emitted a' + a'.  The s_nop covers
+    // the VALU-write -> permlane-read wait states (hipcc pads nothing inside asm).
+    if (LPR >= 32) {
+        float a = x, b = x;
+        asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        x = a + b;
+    }
+    if (LPR >= 64) {
+        float a = x, b = x;
+        asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        x = a + b;
+    }
+    return x;
+}
+
+// best-64 list, sorted ascending across lanes; insert one wave-uniform key
+__device__ __forceinline__ void topk_insert(uint64_t &top, uint64_t c, int lane) {
+    const int posn = __popcll(__ballot(top < c));
+    const uint64_t up = __shfl_up(top, 1);
+    top = lane < posn ? top : (lane == posn ? c : up);
+}
+
+// offer one key per lane; only keys below the current k-th best (tau) are inserted
+__device__ __forceinline__ void topk_offer(uint64_t &top, uint64_t &tau, uint64_t key, int k, int lane) {
+    unsigned long long m = __ballot(key < tau);
+    while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const uint64_t c = __shfl(key, src);
+        if (c < tau) {
+            topk_insert(top, c, lane);
+            tau = __shfl(top, k - 1);
+        }
+    }
+}
+
+__device__ __forceinline__ void store_topk(float *out_dist, int32_t *out_idx, uint64_t *out_keys, long long q, int k,
+                                           uint64_t top, int lane) {
+    if (lane < k) {
+        const bool none = top == KEY_NONE;
+        out_dist[q * k + lane] = none ? __builtin_inff() : float_from_mono((uint32_t)(top >> 32));
+        out_idx[q * k + lane] = none ? -1 : (int32_t)(uint32_t)top;
+        if (out_keys) out_keys[q * k + lane] = top;
+    }
+}
+
+// Query fragment of one lane: columns 4*(li + v*LPR) .. +3, padded so that padding contributes 0
+// (L2: (q - 0) + eps == 0 with q = -eps; cosine: 0).  Cosine fragments are pre-divided by
+// max(||q||, 1e-8) like cosine_similarity does with x1.
+template <int LPR, int VPL, int METRIC>
+__device__ __forceinline__ void load_query(const float *qp, int d, int li, float4 (&qv)[VPL], bool (&act)[VPL]) {
+    const float padv = METRIC == NLSH_METRIC_L2_EPS ? -1e-6f : 0.0f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        const int c0 = 4 * (li + v * LPR);
+        act[v] = c0 < d;
+        qv[v].x = c0 + 0 < d ? qp[c0 + 0] : padv;
+        qv[v].y = c0 + 1 < d ? qp[c0 + 1] : padv;
+        qv[v].z = c0 + 2 < d ? qp[c0 + 2] : padv;
+        qv[v].w = c0 + 3 < d ? qp[c0 + 3] : padv;
+    }
+    if (METRIC == NLSH_METRIC_COSINE) {
+        float ss = 0.0f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v)
+            if (act[v]) { ss = fmaf(qv[v].x, qv[v].x, ss); ss = fmaf(qv[v].y, qv[v].y, ss); ss = fmaf(qv[v].z, qv[v].z, ss); ss = fmaf(qv[v].w, qv[v].w, ss); }
+        ss = group_sum<LPR>(ss);
+        const float nrm = fmaxf(sqrtf(ss), 1e-8f);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) { qv[v].x /= nrm; qv[v].y /= nrm; qv[v].z /= nrm; qv[v].w /= nrm; }
+    }
+}
+
+// lane-partial of one row against one query fragment
+template <int VPL, int METRIC>
+__device__ __forceinline__ float row_partial(const float4 (&qv)[VPL], const bool (&act)[VPL], const float4 (&cv)[VPL]) {
+    float sacc = 0.0f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        if (METRIC == NLSH_METRIC_L2_EPS) {
+            // F.pairwise_distance: || (x1 - x2) + eps ||  (nlsh/data.py:201)
+            float t0 = (qv[v].x - cv[v].x) + 1e-6f, t1 = (qv[v].y - cv[v].y) + 1e-6f;
+            float t2 = (qv[v].z - cv[v].z) + 1e-6f, t3 = (qv[v].w - cv[v].w) + 1e-6f;
+            float part = fmaf(t3, t3, fmaf(t2, t2, fmaf(t1, t1, t0 * t0)));
+            sacc += act[v] ? part : 0.0f;
+        } else {
+            sacc += fmaf(qv[v].w, cv[v].w, fmaf(qv[v].z, cv[v].z, fmaf(qv[v].y, cv[v].y, qv[v].x * cv[v].x)));
+        }
+    }
+    return sacc;
+}
+
+template <int METRIC>
+__device__ __forceinline__ float finish_distance(float acc, float inv_norm) {
+    if (METRIC == NLSH_METRIC_L2_EPS) return sqrtf(acc);
+    return 1.0f - acc * inv_norm;  // 1 - cos (nlsh/data.py:109)
+}
+
+static inline size_t ws_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// entry point of the bucket-major algorithm (scan_bucket.hip)
+struct BucketScanCall {
+    const float *corpus; long long row_stride; int d; const int32_t *gid; const int32_t *uniq; const int32_t *offsets; int nb;
+    const float *inv_norm; const float *queries; long long q_stride; long long Q; const int32_t *qkeys; const int32_t *nkeys;
+    int P, k, metric, seg; float *out_dist; int32_t *out_idx; uint64_t *out_keys; int32_t *out_ncand; int32_t *status;
+    void *workspace; size_t workspace_bytes; long long max_tasks; void *ev_begin; void *ev_end; hipStream_t stream;
+};
+size_t bucket_scan_workspace(long long Q, int P, int k, long long max_tasks, long long n_buckets);
+int bucket_scan_run(const BucketScanCall &c);
+
+}  // namespace nlsh

@@ -5,7 +5,15 @@
 // (:84-87; nlsh/data.py:99-109, 191-201), cat (:88), topk + .tolist() with a device sync per
 // query (:90-91).
 //
-// gfx950 mapping (HBM-bound: 4*d bytes and 3*d flop per candidate, 0.75 flop/B)
+// Two schedules share the arithmetic (scan_common.h), so their results are bit-identical:
+//   algo 0, QUERY-MAJOR (this file): one wavefront per (query, <= seg_rows candidates); every
+//     candidate row is fetched once per query that probes it.  Best when buckets are small and
+//     few queries share a bucket (balanced hash): a query's <= P buckets are walked by one wave.
+//   algo 1, BUCKET-MAJOR (scan_bucket.hip): one wavefront per (bucket segment, group of <= 8
+//     queries probing that bucket); a row tile is fetched once and scored against all queries of
+//     the group from registers, cutting HBM traffic by up to 8x when many queries share buckets.
+//
+// gfx950 mapping of the query-major kernel (HBM-bound: 4*d bytes, 3*d flop per candidate)
 //   * the corpus is bucket-contiguous (nlsh_gather_rows), so a query's candidate list is a
 //     concatenation of <= P contiguous row ranges: streaming, not gathering;
 //   * plan kernel: thread per query; binary search of each key in uniq_keys, prefix of bucket
@@ -21,7 +29,7 @@
 //     (ballot + popcount + one lane shift), so the steady state costs ~3 instructions per tile;
 //   * queries whose candidates span several tasks are combined by a small merge kernel with the
 //     same comparator; nlsh_merge_topk does the same across corpus shards (multi-GPU).
-#include "common.h"
+#include "scan_common.h"
 
 namespace nlsh {
 
@@ -81,13 +89,8 @@ __global__ __launch_bounds__(256) void plan_kernel(ScanArgs a) {
         }
         ns = (C + a.seg - 1) / a.seg;
         a.out_ncand[q] = C;  // n_candidates, indexer.py:71,94
-        if (C == 0) {
-            for (int i = 0; i < a.k; ++i) {
-                a.out_dist[q * a.k + i] = __builtin_inff();
-                a.out_idx[q * a.k + i] = -1;
-                if (a.out_keys) a.out_keys[q * a.k + i] = KEY_NONE;
-            }
-        }
+        if (C == 0)  // no task will touch this query: write the empty result here
+            for (int i = 0; i < a.k; ++i) store_topk(a.out_dist, a.out_idx, a.out_keys, q, a.k, KEY_NONE, i);
     }
     // block-exclusive scan of ns, one atomic per block for the global task base
     int32_t incl = ns;
@@ -112,53 +115,6 @@ __global__ __launch_bounds__(256) void plan_kernel(ScanArgs a) {
             long long t = (long long)tb + s;
             if (t < a.max_tasks) { a.task_q[t] = (int32_t)q; a.task_s[t] = s; }
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------ wave helpers
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
-}
-
-// sum over aligned groups of LPR lanes; every lane of a group receives the same bits
-template <int LPR>
-__device__ __forceinline__ float group_sum(float x) {
-    x += dpp_f<0xB1>(x);                    // quad_perm [1,0,3,2]
-    x += dpp_f<0x4E>(x);                    // quad_perm [2,3,0,1]
-    x += dpp_f<0x141>(x);                   // row_half_mirror
-    x += dpp_f<0x140>(x);                   // row_mirror -> 16-lane sums
-    if (LPR >= 32) x += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));  // lane ^ 16
-    if (LPR >= 64) x += __shfl_xor(x, 32);
-    return x;
-}
-
-// best-64 list, sorted ascending across lanes; insert one wave-uniform key
-__device__ __forceinline__ void topk_insert(uint64_t &top, uint64_t c, int lane) {
-    const int posn = __popcll(__ballot(top < c));
-    const uint64_t up = __shfl_up(top, 1);
-    top = lane < posn ? top : (lane == posn ? c : up);
-}
-
-__device__ __forceinline__ void topk_offer(uint64_t &top, uint64_t &tau, uint64_t key, int k, int lane) {
-    unsigned long long m = __ballot(key < tau);
-    while (m) {
-        const int src = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        const uint64_t c = __shfl(key, src);
-        if (c < tau) {
-            topk_insert(top, c, lane);
-            tau = __shfl(top, k - 1);
-        }
-    }
-}
-
-__device__ __forceinline__ void write_final(const ScanArgs &a, long long q, uint64_t top, int lane) {
-    if (lane < a.k) {
-        const bool none = top == KEY_NONE;
-        a.out_dist[q * a.k + lane] = none ? __builtin_inff() : float_from_mono((uint32_t)(top >> 32));
-        a.out_idx[q * a.k + lane] = none ? -1 : (int32_t)(uint32_t)top;
-        if (a.out_keys) a.out_keys[q * a.k + lane] = top;
     }
 }
 
@@ -189,34 +145,10 @@ __global__ __launch_bounds__(256) void scan_kernel(ScanArgs a) {
     if (lane < a.P) { cum_l = a.pcum[q * a.P + lane]; st_l = a.pstart[q * a.P + lane]; }
     const int np = nk < a.P ? nk : a.P;
 
-    // query fragment: lane li holds columns 4*(li + v*LPR) .. +3
     const int li = lane % LPR, sub = lane / LPR;
-    const int d = a.d;
     float4 qv[VPL];
     bool act[VPL];
-    {
-        const float *qp = a.queries + q * a.q_stride;
-        const float padv = METRIC == NLSH_METRIC_L2_EPS ? -1e-6f : 0.0f;  // makes (q-c)+eps == 0 on padding
-#pragma unroll
-        for (int v = 0; v < VPL; ++v) {
-            const int c0 = 4 * (li + v * LPR);
-            act[v] = c0 < d;
-            qv[v].x = c0 + 0 < d ? qp[c0 + 0] : padv;
-            qv[v].y = c0 + 1 < d ? qp[c0 + 1] : padv;
-            qv[v].z = c0 + 2 < d ? qp[c0 + 2] : padv;
-            qv[v].w = c0 + 3 < d ? qp[c0 + 3] : padv;
-        }
-        if (METRIC == NLSH_METRIC_COSINE) {  // x1 / max(||x1||, eps), as cosine_similarity does
-            float ss = 0.0f;
-#pragma unroll
-            for (int v = 0; v < VPL; ++v)
-                if (act[v]) { ss = fmaf(qv[v].x, qv[v].x, ss); ss = fmaf(qv[v].y, qv[v].y, ss); ss = fmaf(qv[v].z, qv[v].z, ss); ss = fmaf(qv[v].w, qv[v].w, ss); }
-            ss = group_sum<LPR>(ss);
-            const float nrm = fmaxf(sqrtf(ss), 1e-8f);
-#pragma unroll
-            for (int v = 0; v < VPL; ++v) { qv[v].x /= nrm; qv[v].y /= nrm; qv[v].z /= nrm; qv[v].w /= nrm; }
-        }
-    }
+    load_query<LPR, VPL, METRIC>(a.queries + q * a.q_stride, a.d, li, qv, act);
 
     const float4 *corpus4 = reinterpret_cast<const float4 *>(a.corpus);
     const long long stride4 = a.row_stride >> 2;
@@ -242,7 +174,7 @@ __global__ __launch_bounds__(256) void scan_kernel(ScanArgs a) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int j = j0 + u;
-                const int row = __shfl(prow, sub * LPR + (j < LPR ? j : 0));
+                const int row = __shfl(prow, sub * LPR + j);
                 const bool ok = j * RPI + sub < ntile;
                 const float4 *rp = corpus4 + (long long)row * stride4 + li;
 #pragma unroll
@@ -251,34 +183,17 @@ __global__ __launch_bounds__(256) void scan_kernel(ScanArgs a) {
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int j = j0 + u;
-                float sacc = 0.0f;
-#pragma unroll
-                for (int v = 0; v < VPL; ++v) {
-                    if (METRIC == NLSH_METRIC_L2_EPS) {
-                        // F.pairwise_distance: || (x1 - x2) + eps ||  (nlsh/data.py:201)
-                        float t0 = (qv[v].x - cv[u][v].x) + 1e-6f, t1 = (qv[v].y - cv[u][v].y) + 1e-6f;
-                        float t2 = (qv[v].z - cv[u][v].z) + 1e-6f, t3 = (qv[v].w - cv[u][v].w) + 1e-6f;
-                        float part = fmaf(t3, t3, fmaf(t2, t2, fmaf(t1, t1, t0 * t0)));
-                        sacc += act[v] ? part : 0.0f;
-                    } else {
-                        float part = fmaf(qv[v].w, cv[u][v].w, fmaf(qv[v].z, cv[u][v].z, fmaf(qv[v].y, cv[u][v].y, qv[v].x * cv[u][v].x)));
-                        sacc += part;
-                    }
-                }
-                const float tot = group_sum<LPR>(sacc);
-                if (li == j) mydist = tot;
+                const float tot = group_sum<LPR>(row_partial<VPL, METRIC>(qv, act, cv[u]));
+                if (li == j0 + u) mydist = tot;
             }
         }
-        float dist;
-        if (METRIC == NLSH_METRIC_L2_EPS) dist = sqrtf(mydist);
-        else dist = 1.0f - mydist * myinv;                // 1 - cos (nlsh/data.py:109)
+        const float dist = finish_distance<METRIC>(mydist, myinv);
         const uint64_t key = valid ? make_key(dist, mygid) : KEY_NONE;
         topk_offer(top, tau, key, a.k, lane);
     }
 
     const int ns = __builtin_amdgcn_readfirstlane(a.nseg[q]);
-    if (ns == 1) write_final(a, q, top, lane);
+    if (ns == 1) store_topk(a.out_dist, a.out_idx, a.out_keys, q, a.k, top, lane);
     else if (lane < a.k) a.partial[t * a.k + lane] = top;
 }
 
@@ -297,7 +212,7 @@ __global__ __launch_bounds__(256) void merge_segments_kernel(ScanArgs a) {
         const uint64_t key = lane < a.k ? a.partial[t * a.k + lane] : KEY_NONE;
         topk_offer(top, tau, key, a.k, lane);
     }
-    write_final(a, q, top, lane);
+    store_topk(a.out_dist, a.out_idx, a.out_keys, q, a.k, top, lane);
 }
 
 __global__ __launch_bounds__(256) void merge_shards_kernel(const uint64_t *keys_in, int G, long long Q, int k,
@@ -313,28 +228,22 @@ __global__ __launch_bounds__(256) void merge_shards_kernel(const uint64_t *keys_
         topk_offer(top, tau, key, k, lane);
         if (ncand_in) nc += ncand_in[(long long)g * Q + q];
     }
-    if (lane < k) {
-        const bool none = top == KEY_NONE;
-        out_dist[q * k + lane] = none ? __builtin_inff() : float_from_mono((uint32_t)(top >> 32));
-        out_idx[q * k + lane] = none ? -1 : (int32_t)(uint32_t)top;
-    }
+    store_topk(out_dist, out_idx, nullptr, q, k, top, lane);
     if (out_ncand && ncand_in && lane == 0) out_ncand[q] = nc;
 }
-
-static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct ScanWs {
     size_t pstart, pcum, nseg, tbase, task_q, task_s, partial, total;
 };
 static void scan_layout(long long Q, int P, int k, long long max_tasks, ScanWs *w) {
     size_t o = 0;
-    w->pstart = o; o += al((size_t)Q * P * 4);
-    w->pcum = o;   o += al((size_t)Q * P * 4);
-    w->nseg = o;   o += al((size_t)Q * 4);
-    w->tbase = o;  o += al((size_t)Q * 4);
-    w->task_q = o; o += al((size_t)max_tasks * 4);
-    w->task_s = o; o += al((size_t)max_tasks * 4);
-    w->partial = o; o += al((size_t)max_tasks * k * 8);
+    w->pstart = o; o += ws_align((size_t)Q * P * 4);
+    w->pcum = o;   o += ws_align((size_t)Q * P * 4);
+    w->nseg = o;   o += ws_align((size_t)Q * 4);
+    w->tbase = o;  o += ws_align((size_t)Q * 4);
+    w->task_q = o; o += ws_align((size_t)max_tasks * 4);
+    w->task_s = o; o += ws_align((size_t)max_tasks * 4);
+    w->partial = o; o += ws_align((size_t)max_tasks * k * 8);
     w->total = o;
 }
 
@@ -351,24 +260,26 @@ static void launch_scan(const ScanArgs &a, int d4, unsigned grid, hipStream_t s)
 
 using namespace nlsh;
 
-extern "C" size_t nlsh_scan_workspace(int64_t Q, int P, int k, int64_t max_tasks) {
-    if (Q < 0 || P < 1 || k < 1 || max_tasks < 0) { set_error("scan_workspace: bad sizes"); return 0; }
+extern "C" size_t nlsh_scan_workspace(int64_t Q, int P, int k, int64_t max_tasks, int64_t n_buckets) {
+    if (Q < 0 || P < 1 || k < 1 || max_tasks < 0 || n_buckets < 0) { set_error("scan_workspace: bad sizes"); return 0; }
     ScanWs w;
     scan_layout(Q, P, k, max_tasks, &w);
-    return w.total;
+    const size_t b = bucket_scan_workspace(Q, P, k, max_tasks, n_buckets);
+    return w.total > b ? w.total : b;
 }
 
 extern "C" int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, int d, const int32_t *gid,
                               const int32_t *uniq_keys, const int32_t *offsets, int32_t n_buckets, const float *inv_norm,
                               const float *queries, int64_t q_stride, int64_t Q, const int32_t *qkeys, const int32_t *nkeys,
-                              int P, int k, int metric, int seg_rows, float *out_dist, int32_t *out_idx, uint64_t *out_keys,
-                              int32_t *out_ncand, int32_t *status, void *workspace, size_t workspace_bytes, int64_t max_tasks,
-                              void *ev_scan_begin, void *ev_scan_end, nlsh_stream_t stream) {
+                              int P, int k, int metric, int algo, int seg_rows, float *out_dist, int32_t *out_idx,
+                              uint64_t *out_keys, int32_t *out_ncand, int32_t *status, void *workspace, size_t workspace_bytes,
+                              int64_t max_tasks, void *ev_scan_begin, void *ev_scan_end, nlsh_stream_t stream) {
     NLSH_REQUIRE(Q >= 0 && Q < (1ll << 31), NLSH_E_INVALID, "scan_topk: Q=%lld", (long long)Q);
     NLSH_REQUIRE(d >= 1 && d <= NLSH_MAX_DIM, NLSH_E_UNSUPPORTED, "scan_topk: d=%d not in [1,%d]", d, NLSH_MAX_DIM);
     NLSH_REQUIRE(k >= 1 && k <= NLSH_MAX_K, NLSH_E_UNSUPPORTED, "scan_topk: k=%d not in [1,%d]", k, NLSH_MAX_K);
     NLSH_REQUIRE(P >= 1 && P <= NLSH_MAX_PROBES, NLSH_E_UNSUPPORTED, "scan_topk: P=%d not in [1,%d]", P, NLSH_MAX_PROBES);
     NLSH_REQUIRE(metric == NLSH_METRIC_L2_EPS || metric == NLSH_METRIC_COSINE, NLSH_E_INVALID, "scan_topk: metric=%d", metric);
+    NLSH_REQUIRE(algo == NLSH_SCAN_QUERY_MAJOR || algo == NLSH_SCAN_BUCKET_MAJOR, NLSH_E_INVALID, "scan_topk: algo=%d", algo);
     NLSH_REQUIRE(n_buckets >= 0 && max_tasks >= 0 && seg_rows >= 0, NLSH_E_INVALID, "scan_topk: negative size");
     if (Q == 0) return NLSH_OK;
     NLSH_REQUIRE(queries && qkeys && nkeys && out_dist && out_idx && out_ncand && status && workspace, NLSH_E_INVALID, "scan_topk: null pointer");
@@ -379,10 +290,18 @@ extern "C" int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, in
     NLSH_REQUIRE(q_stride >= d, NLSH_E_INVALID, "scan_topk: q_stride < d");
     if (seg_rows == 0) seg_rows = 512;
     seg_rows = (seg_rows + 63) / 64 * 64;
+    hipStream_t s = (hipStream_t)stream;
+
+    if (algo == NLSH_SCAN_BUCKET_MAJOR) {
+        BucketScanCall c = {corpus_sorted, row_stride, d, gid, uniq_keys, offsets, n_buckets, inv_norm, queries, q_stride, Q,
+                            qkeys, nkeys, P, k, metric, seg_rows, out_dist, out_idx, out_keys, out_ncand, status, workspace,
+                            workspace_bytes, max_tasks, ev_scan_begin, ev_scan_end, s};
+        return bucket_scan_run(c);
+    }
+
     ScanWs w;
     scan_layout(Q, P, k, max_tasks, &w);
     NLSH_REQUIRE(workspace_bytes >= w.total, NLSH_E_WORKSPACE, "scan_topk: workspace %zu < %zu", workspace_bytes, w.total);
-
     ScanArgs a;
     a.corpus = corpus_sorted; a.row_stride = row_stride; a.d = d; a.gid = gid; a.uniq = uniq_keys; a.offsets = offsets;
     a.nb = n_buckets; a.inv_norm = inv_norm; a.queries = queries; a.q_stride = q_stride; a.Q = Q; a.qkeys = qkeys;
@@ -393,7 +312,6 @@ extern "C" int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, in
     a.tbase = (int32_t *)(base + w.tbase); a.task_q = (int32_t *)(base + w.task_q); a.task_s = (int32_t *)(base + w.task_s);
     a.partial = (uint64_t *)(base + w.partial);
 
-    hipStream_t s = (hipStream_t)stream;
     NLSH_CHECK_HIP(hipMemsetAsync(status, 0, 2 * sizeof(int32_t), s));
     hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s, a);
     if (max_tasks > 0) {

@@ -85,17 +85,18 @@ def build_index(indexes, cuda=True) -> Dict[int, torch.Tensor]:
 class Indexer:
 
     def __init__(self, hashing, candidate_vectors_gpu, distance_func, compat=True, metric: Optional[str] = None,
-                 seg_rows: int = 0, id_base: int = 0):
+                 seg_rows: int = 0, id_base: int = 0, algo: Optional[str] = None):
         self._hashing = hashing
         self._candidate_vectors_gpu = candidate_vectors_gpu
         self._distance_func = distance_func
         self.compat = compat
         self.metric = metric or metric_of(distance_func)
         self.seg_rows = seg_rows
+        self.algo = algo            # None = choose per batch; "query" | "bucket" force a schedule
         self.id_base = int(id_base)
         self._index2row = None
         self._ws = None
-        self._max_tasks = None
+        self._max_tasks = {}
         self._build_index()
 
     # ------------------------------------------------------------------ build
@@ -157,11 +158,26 @@ class Indexer:
         return keys_to_sets(keys, nkeys, self._hashing.key_mode)
 
     # ------------------------------------------------------------------ query
-    def _estimate_tasks(self, Q, P, seg):
+    def _size_biased_bucket(self):
         s = self.bucket_sizes.astype(np.float64)
         n = max(float(s.sum()), 1.0)
-        biased = float((s * s).sum() / n) if len(s) else 0.0          # expected size of the bucket a point lands in
-        est = Q * (1.0 + min(P, 4) * biased / seg)
+        return float((s * s).sum() / n) if len(s) else 0.0            # expected size of the bucket a point lands in
+
+    def choose_algo(self, Q, P):
+        """Bucket-major pays when a corpus row is a candidate of several queries of the batch:
+        expected (query, probe) pairs per row ~ Q * P * E[bucket size of a row] / N."""
+        if self.algo is not None:
+            return _capi.SCAN_BUCKET_MAJOR if self.algo == "bucket" else _capi.SCAN_QUERY_MAJOR
+        n = max(float(self.bucket_sizes.sum()), 1.0)
+        reuse = Q * P * self._size_biased_bucket() / n
+        return _capi.SCAN_BUCKET_MAJOR if reuse >= 4.0 else _capi.SCAN_QUERY_MAJOR
+
+    def _estimate_tasks(self, Q, P, seg, algo):
+        biased = self._size_biased_bucket()
+        if algo == _capi.SCAN_BUCKET_MAJOR:
+            est = Q * min(P, 4) * (1.0 / 4 + biased / seg / 4) + self.n_buckets
+        else:
+            est = Q * (1.0 + min(P, 4) * biased / seg)
         return int(min(max(1.5 * est + 1024, Q + 1024), 2 ** 31 - 8))
 
     def scan_tensors(self, query_vectors, keys, nkeys, k=10, want_keys=False, check=True, events=None):
@@ -188,17 +204,18 @@ class Indexer:
         ncand = torch.empty((Q,), dtype=torch.int32, device=dev)
         status = torch.empty((2,), dtype=torch.int32, device=dev)
         metric = _capi.METRIC_L2_EPS if self.metric == "l2" else _capi.METRIC_COSINE
-        if self._max_tasks is None:
-            self._max_tasks = self._estimate_tasks(Q, P, seg)
+        algo = self.choose_algo(Q, P)
+        if algo not in self._max_tasks:
+            self._max_tasks[algo] = self._estimate_tasks(Q, P, seg, algo)
         while True:
-            max_tasks = self._max_tasks
-            ws_bytes = L.nlsh_scan_workspace(Q, P, k, max_tasks)
+            max_tasks = self._max_tasks[algo]
+            ws_bytes = L.nlsh_scan_workspace(Q, P, k, max_tasks, self.n_buckets)
             if self._ws is None or self._ws.numel() < ws_bytes or self._ws.device != dev:
                 self._ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
             _capi.check(L.nlsh_scan_topk(
                 _capi.ptr(self.corpus_sorted), self.row_stride, d, _capi.ptr(self.gid), _capi.ptr(self.uniq_keys),
                 _capi.ptr(self.offsets), self.n_buckets, _capi.ptr(self.inv_norm), _capi.ptr(q), q.stride(0) if Q else d, Q,
-                _capi.ptr(keys), _capi.ptr(nkeys), P, k, metric, seg, _capi.ptr(out_dist), _capi.ptr(out_idx),
+                _capi.ptr(keys), _capi.ptr(nkeys), P, k, metric, algo, seg, _capi.ptr(out_dist), _capi.ptr(out_idx),
                 _capi.ptr(out_keys), _capi.ptr(ncand), _capi.ptr(status), _capi.ptr(self._ws), self._ws.numel(), max_tasks,
                 events[0].cuda_event if events else None, events[1].cuda_event if events else None, _stream(dev)))
             if not check or Q == 0:
@@ -206,8 +223,9 @@ class Indexer:
             needed, overflow = status.cpu().tolist()
             if not overflow:
                 break
-            self._max_tasks = int(needed * 1.25) + 1024      # segment table too small: grow and repeat
+            self._max_tasks[algo] = int(needed * 1.25) + 1024      # segment table too small: grow and repeat
         self.last_status = status
+        self.last_algo = algo
         return out_dist, out_idx, ncand, out_keys
 
     def query_tensors(self, query_vectors, k=10, hash_times=10, seed=None, want_keys=False, check=True, events=None):

@@ -159,8 +159,9 @@ def test_build_index_reference_vector_and_random():
 
 
 # ----------------------------------------------------------------------------- a8-a10 scan on injected keys
+@pytest.mark.parametrize("algo", ["query", "bucket"])
 @pytest.mark.parametrize("name", ["l2_small", "cos_small", "l2_k3"])
-def test_scan_golden_injected_keys(name):
+def test_scan_golden_injected_keys(name, algo):
     from nlsh_amd.data import Glove, SIFT
     from nlsh_amd.indexer import Indexer
     meta = json.load(open(os.path.join(G, "g5_query.json")))[name]
@@ -168,7 +169,7 @@ def test_scan_golden_injected_keys(name):
     corpus, queries, Ws, bs = cases.g5_inputs(meta)
     cos = meta["metric"] == "cosine"
     hashing = make_hashing(meta["d"], (64, 64), meta["H"], Ws, bs, tanh=cos)
-    indexer = Indexer(hashing, dev(corpus), Glove.distance if cos else SIFT.distance)
+    indexer = Indexer(hashing, dev(corpus), Glove.distance if cos else SIFT.distance, algo=algo)
     ck = indexer.corpus_keys.cpu().numpy()
     assert (ck == g[name + "/corpus_keys"]).mean() > 0.999
     if not np.array_equal(ck, g[name + "/corpus_keys"]):        # a |z|~0 flip: rebuild on the reference's keys
@@ -205,8 +206,9 @@ SCAN_CASES = [
 ]
 
 
+@pytest.mark.parametrize("algo", ["query", "bucket"])
 @pytest.mark.parametrize("metric,d,N,Q,H,k,seg,P", SCAN_CASES)
-def test_scan_vs_oracle_shapes(metric, d, N, Q, H, k, seg, P):
+def test_scan_vs_oracle_shapes(metric, d, N, Q, H, k, seg, P, algo):
     from nlsh_amd.data import Glove, SIFT
     from nlsh_amd.indexer import Indexer
     rng = np.random.default_rng(d * 7 + N)
@@ -215,7 +217,8 @@ def test_scan_vs_oracle_shapes(metric, d, N, Q, H, k, seg, P):
     corpus[N // 2:N // 2 + 25] = corpus[:25]                      # exact distance ties
     Ws, bs = synth.make_weights([d, 64, H], seed=d)
     hashing = make_hashing(d, (64,), H, Ws, bs, compat=False)
-    indexer = Indexer(hashing, dev(corpus), SIFT.distance if metric == "l2" else Glove.distance, compat=False, seg_rows=seg)
+    indexer = Indexer(hashing, dev(corpus), SIFT.distance if metric == "l2" else Glove.distance, compat=False, seg_rows=seg,
+                      algo=algo)
     ck = indexer.corpus_keys.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
     perm, uniq, offs = oracle.build_csr(ck)
     assert np.array_equal(indexer.perm.cpu().numpy(), perm)
@@ -275,9 +278,10 @@ def test_task_table_overflow_is_detected_and_retried():
     Ws, bs = synth.make_weights([d, 64, H], seed=3)
     hashing = make_hashing(d, (64,), H, Ws, bs)
     indexer = Indexer(hashing, dev(corpus), SIFT.distance, seg_rows=64)
-    indexer._max_tasks = 5                                          # far too small: must grow, not truncate
+    for algo in (0, 1):
+        indexer._max_tasks[algo] = 5                                # far too small: must grow, not truncate
     ids, nc = indexer.query(dev(queries), k=10, hash_times=1)
-    assert indexer._max_tasks > 5
+    assert indexer._max_tasks[indexer.last_algo] > 5
     ox = oracle.OracleIndexer(Ws, bs, corpus)
     oids, onc = ox.query(queries, k=10, hash_times=1)
     assert nc == onc
@@ -337,3 +341,20 @@ def test_sharded_scan_plus_merge_equals_single_index(G):
     assert torch.equal(nm, n1)                                      # candidate counts add up exactly
     assert torch.equal(im, i1)                                      # same comparator -> identical ids
     assert torch.equal(dm, d1)                                      # and bit-identical distances
+
+
+def test_both_schedules_are_bit_identical():
+    """Query-major and bucket-major share the arithmetic: same distances (bitwise), ids, counts."""
+    from nlsh_amd.data import Glove, SIFT
+    from nlsh_amd.indexer import Indexer
+    for metric, d, fn in (("l2", 128, SIFT.distance), ("cosine", 100, Glove.distance), ("l2", 200, SIFT.distance)):
+        gen = synth.sift_like if metric == "l2" else synth.glove_like
+        corpus, queries = gen(40000, d, seed=5), gen(700, d, seed=6)
+        Ws, bs = synth.make_weights([d, 64, 7], seed=5)
+        hashing = make_hashing(d, (64,), 7, Ws, bs)
+        out = []
+        for algo in ("query", "bucket"):
+            ix = Indexer(hashing, dev(corpus), fn, algo=algo, seg_rows=128)
+            out.append(ix.query_tensors(dev(queries), k=10, hash_times=8, seed=3, want_keys=True))
+        for a, b in zip(out[0], out[1]):
+            assert torch.equal(a, b)
