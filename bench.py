@@ -140,7 +140,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    overflow = int(indexer.last_status.cpu()[1])
+    n_tasks, overflow = (int(v) for v in indexer.last_status.cpu())
     assert overflow == 0, "segment table overflow inside the timed region"
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -185,7 +185,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "bscan2_kernel<32,1,L2,8> (bucket-major)" if indexer.last_algo == 1 else "scan_kernel<32,1,L2> (query-major)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms,
-                         "sum_candidates_per_launch": sum_c_local},
+                         "sum_candidates_per_launch": sum_c_local, "tasks_per_launch": n_tasks},
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, corpus_h, queries_h, Ws, bs, indexer, hashing, queries, steps)

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void bscatter_kernel(BArgs a) {
 template <int LPR, int VPL, int METRIC, int QB, bool FULL>
 __device__ __forceinline__ void bscan2_task(const BArgs &a, long long t, int pair0, int nq, int row0, int nrows, int lane) {
     constexpr int RPI = 64 / LPR;
-    constexpr int U = (VPL == 1) ? 8 : (VPL == 2 ? 4 : 2);
+    constexpr int U = (VPL == 1) ? 4 : (VPL == 2 ? 2 : 1);  // wave-loads per pipeline stage (two stages in flight)
     const int li = lane % LPR, sub = lane / LPR;
     float4 qv[QB][VPL];
     bool act[VPL];
@@ -151,51 +151,72 @@ __device__ __forceinline__ void bscan2_task(const BArgs &a, long long t, int pai
         load_query<LPR, VPL, METRIC>(a.queries + (long long)qi * a.q_stride, a.d, li, qv[jq], act);
     }
 
-    const float4 *corpus4 = reinterpret_cast<const float4 *>(a.corpus);
+    // The segment is walked in groups of U wave-loads (U*RPI rows); groups are software-pipelined
+    // through two register sets so the next group's HBM/L2 latency hides under the current group's
+    // QB*U distance evaluations.  LPR/U groups make one 64-row tile (one candidate per lane).
+    constexpr int GPT = LPR / U;
+    const float4 *seg4 = reinterpret_cast<const float4 *>(a.corpus) + (long long)row0 * (a.row_stride >> 2) + li;
     const long long stride4 = a.row_stride >> 2;
-    for (int tile0 = 0; tile0 < nrows; tile0 += 64) {
-        const int ntile = min(64, nrows - tile0);
-        const int myc = li * RPI + sub;
-        const bool valid = myc < ntile;
-        const int prow = row0 + tile0 + (valid ? myc : 0);
-        const int32_t mygid = valid ? a.gid[prow] : -1;
-        float myinv = 0.0f;
-        if (METRIC == NLSH_METRIC_COSINE) myinv = valid ? a.inv_norm[prow] : 0.0f;
-        float mydist[QB];
+    const int G = (nrows + U * RPI - 1) / (U * RPI);
+    const int myc = li * RPI + sub;  // candidate of a tile this lane owns
+    float mydist[QB];
+    int32_t mygid = -1;
+    float myinv = 0.0f;
+    bool valid = false;
+
+    auto load_group = [&](float4 (&cv)[U][VPL], int g) {
 #pragma unroll
-        for (int jq = 0; jq < QB; ++jq) mydist[jq] = __builtin_inff();
-        const float4 *tile4 = corpus4 + (long long)(row0 + tile0) * stride4 + li;
-        for (int j0 = 0; j0 * RPI < ntile; j0 += U) {
-            float4 cv[U][VPL];
+        for (int u = 0; u < U; ++u) {
+            const int r = (g * U + u) * RPI + sub;  // row of the segment this lane group covers
+            const bool ok = r < nrows;
+            const float4 *rp = seg4 + (long long)r * stride4;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int r = (j0 + u) * RPI + sub;  // row of the tile this lane group covers
-                const bool ok = r < ntile;
-                const float4 *rp = tile4 + (long long)r * stride4;
+            for (int v = 0; v < VPL; ++v)
+                cv[u][v] = (ok && act[v]) ? rp[v * LPR] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto compute_group = [&](const float4 (&cv)[U][VPL], int g) {
+        const int gi = g % GPT;
+        if (gi == 0) {  // tile begin
+            const int tile0 = (g / GPT) * 64;
+            valid = tile0 + myc < nrows;
+            const int prow = row0 + tile0 + (valid ? myc : 0);
+            mygid = valid ? a.gid[prow] : -1;
+            if (METRIC == NLSH_METRIC_COSINE) myinv = valid ? a.inv_norm[prow] : 0.0f;
 #pragma unroll
-                for (int v = 0; v < VPL; ++v)
-                    cv[u][v] = (ok && act[v]) ? rp[v * LPR] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int jq = 0; jq < QB; ++jq) mydist[jq] = __builtin_inff();
+        }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool mine = li == j0 + u;
+        for (int u = 0; u < U; ++u) {
+            const bool mine = li == gi * U + u;
 #pragma unroll
-                for (int jq = 0; jq < QB; ++jq) {
-                    if (FULL || jq < nq) {
-                        const float tot = group_sum<LPR>(row_partial<VPL, METRIC>(qv[jq], act, cv[u]));
-                        mydist[jq] = mine ? tot : mydist[jq];
-                    }
+            for (int jq = 0; jq < QB; ++jq) {
+                if (FULL || jq < nq) {
+                    const float tot = group_sum<LPR>(row_partial<VPL, METRIC>(qv[jq], act, cv[u]));
+                    mydist[jq] = mine ? tot : mydist[jq];
                 }
             }
         }
+        if (gi == GPT - 1 || g == G - 1) {  // tile end: offer this lane's candidate to every query's list
 #pragma unroll
-        for (int jq = 0; jq < QB; ++jq) {
-            if (FULL || jq < nq) {
-                const float dist = finish_distance<METRIC>(mydist[jq], myinv);
-                const uint64_t key = valid ? make_key(dist, mygid) : KEY_NONE;
-                topk_offer(top[jq], tau[jq], key, a.k, lane);
+            for (int jq = 0; jq < QB; ++jq) {
+                if (FULL || jq < nq) {
+                    const float dist = finish_distance<METRIC>(mydist[jq], myinv);
+                    const uint64_t key = valid ? make_key(dist, mygid) : KEY_NONE;
+                    topk_offer(top[jq], tau[jq], key, a.k, lane);
+                }
             }
         }
+    };
+
+    float4 cvA[U][VPL], cvB[U][VPL];
+    if (G > 0) load_group(cvA, 0);
+    for (int g = 0; g < G; g += 2) {
+        if (g + 1 < G) load_group(cvB, g + 1);
+        compute_group(cvA, g);
+        if (g + 1 >= G) break;
+        if (g + 2 < G) load_group(cvA, g + 2);
+        compute_group(cvB, g + 1);
     }
 #pragma unroll
     for (int jq = 0; jq < QB; ++jq)
