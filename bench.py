@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--hash-times", type=int, default=10)
     ap.add_argument("--seg-rows", type=int, default=0)
-    ap.add_argument("--algo", default=None, choices=["query", "bucket"], help="force a scan schedule (default: auto)")
+    ap.add_argument("--algo", default=None, choices=["query", "bucket", "tiled"], help="force a scan schedule (default: auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--random-init", action="store_true", help="ignore the learned-hash checkpoint")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
@@ -182,7 +182,7 @@ def main():
                        "n_buckets": stats["n_indexes"], "bucket_mean": stats["mean"], "bucket_median": stats["median"],
                        "bucket_max": stats["max"], "mean_candidates_per_query": mean_c,
                        "index_build_s": build_s, "api_list_qps": api_qps},
-            "roofline": {"bound": "hbm", "kernel": "bscan2_kernel<32,1,L2,8> (bucket-major)" if indexer.last_algo == 1 else "scan_kernel<32,1,L2> (query-major)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": {0: "scan_kernel<32,1,L2> (query-major)", 1: "bscan2_kernel<32,1,L2,8> (bucket-major)", 2: "bscan3_kernel<L2> (bucket-major, LDS-tiled)"}[indexer.last_algo], "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms,
                          "sum_candidates_per_launch": sum_c_local, "tasks_per_launch": n_tasks},

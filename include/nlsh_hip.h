@@ -42,8 +42,10 @@ enum {
 enum { NLSH_ACT_SIGMOID = 0, NLSH_ACT_TANH = 1 };      /* nlsh/hashings.py:22-26 (tanh_output) */
 enum { NLSH_KEY_REF_INT16 = 0, NLSH_KEY_FULL = 1 };    /* nlsh/utils.pyx:7-15 (int16 wrap) | eval.py:49-53 */
 enum { NLSH_METRIC_L2_EPS = 0, NLSH_METRIC_COSINE = 1 }; /* nlsh/data.py:191-201 | 99-109 */
-/* schedules of nlsh_scan_topk (identical results): one wave per (query, segment) | per (bucket segment, <=8 queries) */
-enum { NLSH_SCAN_QUERY_MAJOR = 0, NLSH_SCAN_BUCKET_MAJOR = 1 };
+/* schedules of nlsh_scan_topk: one wave per (query, segment) | one wave per (bucket segment, <= 8 queries) |
+ * one workgroup per (bucket segment, <= 32 queries) with the row tile staged through LDS.  0 and 1 give
+ * bit-identical results; 2 sums each distance in k order (bit-identical to the oracle), ids agree except fp32 near-ties. */
+enum { NLSH_SCAN_QUERY_MAJOR = 0, NLSH_SCAN_BUCKET_MAJOR = 1, NLSH_SCAN_BUCKET_TILED = 2 };
 
 #define NLSH_MAX_LAYERS 8   /* Linear layers incl. the output layer */
 #define NLSH_MAX_HASH_BITS 32
@@ -120,7 +122,7 @@ int nlsh_gather_rows(const float *corpus, int64_t src_stride, int d, const int32
  * bucket lookup (:68), gather (:77-82), distance (:84-87, nlsh/data.py:99-109,191-201),
  * cat (:88), topk + id map (:90-91), n_candidates (:71,94).
  * ------------------------------------------------------------------------------------------- */
-size_t nlsh_scan_workspace(int64_t Q, int P, int k, int64_t max_tasks, int64_t n_buckets);
+size_t nlsh_scan_workspace(int64_t Q, int P, int k, int64_t max_tasks, int64_t n_buckets, int d);
 
 /* corpus_sorted [dev] fp32 [N, row_stride] bucket-contiguous (nlsh_gather_rows), gid [dev] [N],
  * uniq_keys [dev] [n_buckets] ascending, offsets [dev] [n_buckets+1], inv_norm [dev] [N] (cosine

@@ -45,6 +45,8 @@ struct BArgs {
     int4 *task;
     uint64_t *partial;
     long long max_tasks;
+    float *qpad;  // tiled variant: queries padded to d4p*4 floats (L2: pad = -eps; cosine: pre-normalised, pad = 0)
+    int d4p;
 };
 
 __global__ __launch_bounds__(256) void bplan_kernel(BArgs a) {
@@ -242,6 +244,179 @@ __global__ __launch_bounds__(256) void bscan2_kernel(BArgs a) {
     else bscan2_task<LPR, VPL, METRIC, QB, false>(a, t, pair0, nq, row0, nrows, lane);
 }
 
+// ------------------------------------------------------------------------------------ tiled variant
+// NLSH_SCAN_BUCKET_TILED: one WORKGROUP per task = (bucket segment, group of <= 32 queries).
+// The 64-row tile is staged once through LDS (coalesced 16-byte global loads -> ds_write_b128, row
+// stride 33 slots = conflict-free column reads) and every lane then OWNS ONE ROW: it walks the row
+// in k order and updates 8 query accumulators per wave, the query values arriving as wave-uniform
+// scalar loads (s_load from a padded, pre-normalised copy of the queries).  No cross-lane reduction
+// at all: 3 VALU per element and query for L2 ((q-c), +eps, fma), 1 for cosine; the distance of
+// lane l's row is a k-ascending fmaf chain, bit-identical to the oracle's scalar loop.  Four waves
+// share the tile, so a row is fetched from HBM/L2 once per 32 queries.  The next stage's global
+// loads are issued before the current stage is computed (T14 split: load early, ds_write late).
+typedef const __attribute__((address_space(4))) float *const_f32p;
+
+__global__ __launch_bounds__(64) void bprep_kernel(BArgs a, int metric) {
+    const long long q = blockIdx.x;
+    const int lane = threadIdx.x;
+    const float *qp = a.queries + q * a.q_stride;
+    float *dst = a.qpad + q * (long long)a.d4p * 4;
+    const int n = a.d4p * 4;
+    if (metric == NLSH_METRIC_L2_EPS) {
+        for (int e = lane; e < n; e += 64) dst[e] = e < a.d ? qp[e] : -1e-6f;  // (q - 0) + eps == 0 on padding
+    } else {
+        float ss = 0.0f;
+        for (int e = lane; e < a.d; e += 64) ss = fmaf(qp[e], qp[e], ss);
+        for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
+        const float nrm = fmaxf(sqrtf(ss), 1e-8f);  // x1 / max(||x1||, eps), as cosine_similarity does
+        for (int e = lane; e < n; e += 64) dst[e] = e < a.d ? qp[e] / nrm : 0.0f;
+    }
+}
+
+template <int QW>
+struct QChunk { float v[QW][4]; };  // wave-uniform: lives in SGPRs
+
+template <int QW, bool FULL>
+__device__ __forceinline__ void load_qchunk(QChunk<QW> &qc, const const_f32p (&qs)[QW], int nqw, int c) {
+#pragma unroll
+    for (int jq = 0; jq < QW; ++jq)
+        if (FULL || jq < nqw) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qc.v[jq][e] = qs[jq][4 * c + e];  // one s_load_dwordx4 per query
+        }
+}
+
+template <int METRIC, int QW, bool FULL>
+__device__ __forceinline__ void apply_qchunk(const QChunk<QW> &qc, const float4 rv, int nqw, float (&acc)[QW]) {
+#pragma unroll
+    for (int jq = 0; jq < QW; ++jq) {
+        if (FULL || jq < nqw) {
+            const float q0 = qc.v[jq][0], q1 = qc.v[jq][1], q2 = qc.v[jq][2], q3 = qc.v[jq][3];
+            if (METRIC == NLSH_METRIC_L2_EPS) {
+                // F.pairwise_distance: || (x1 - x2) + eps ||, summed in k order (nlsh/data.py:201)
+                const float t0 = (q0 - rv.x) + 1e-6f, t1 = (q1 - rv.y) + 1e-6f, t2 = (q2 - rv.z) + 1e-6f, t3 = (q3 - rv.w) + 1e-6f;
+                acc[jq] = fmaf(t3, t3, fmaf(t2, t2, fmaf(t1, t1, fmaf(t0, t0, acc[jq]))));
+            } else {
+                acc[jq] = fmaf(q3, rv.w, fmaf(q2, rv.z, fmaf(q1, rv.y, fmaf(q0, rv.x, acc[jq]))));
+            }
+        }
+    }
+}
+
+// Chunks are processed in pairs through two scalar register sets: the s_loads of chunk c+1 are
+// issued before chunk c is evaluated, so the scalar-cache latency hides under the VALU work.
+template <int METRIC, int QW, bool FULL>
+__device__ __forceinline__ void tile_accumulate(const float4 *lds_row, int nchunk, const const_f32p (&qs)[QW], int nqw, float (&acc)[QW]) {
+    QChunk<QW> qa, qb;
+    load_qchunk<QW, FULL>(qa, qs, nqw, 0);
+    for (int c = 0; c < nchunk; c += 2) {
+        const float4 rv0 = lds_row[c];
+        const bool has1 = c + 1 < nchunk;
+        const float4 rv1 = lds_row[has1 ? c + 1 : c];
+        load_qchunk<QW, FULL>(qb, qs, nqw, has1 ? c + 1 : c);
+        apply_qchunk<METRIC, QW, FULL>(qa, rv0, nqw, acc);
+        if (!has1) break;
+        load_qchunk<QW, FULL>(qa, qs, nqw, c + 2 < nchunk ? c + 2 : c);
+        apply_qchunk<METRIC, QW, FULL>(qb, rv1, nqw, acc);
+    }
+}
+
+// QW queries per wave, NW waves per workgroup: QW*NW queries per task.
+template <int METRIC, int QW, int NW>
+__global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
+    constexpr int NT = 64 * NW;         // threads per workgroup
+    constexpr int KB = 32;              // 16-byte chunks per k-block (128 floats)
+    constexpr int RS = KB + 1;          // LDS row stride in 16-byte slots (odd -> conflict-free ds_read_b128 down a column)
+    constexpr int SPT = 64 * KB / NT;   // staged 16-byte words per thread and stage
+    __shared__ float4 tile[64 * RS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long t = blockIdx.x;
+    long long ntasks = a.status[0];
+    if (ntasks > a.max_tasks) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.status[1] = 1;  // incomplete: caller must retry
+        ntasks = a.max_tasks;
+    }
+    if (t >= ntasks) return;
+    const int4 desc = a.task[t];
+    const int pair0 = __builtin_amdgcn_readfirstlane(desc.x);
+    const int nq = __builtin_amdgcn_readfirstlane(desc.y);
+    const int row0 = __builtin_amdgcn_readfirstlane(desc.z);
+    const int nrows = __builtin_amdgcn_readfirstlane(desc.w);
+    int nqw = nq - wave * QW;
+    nqw = __builtin_amdgcn_readfirstlane(nqw < 0 ? 0 : (nqw > QW ? QW : nqw));
+
+    const_f32p qs[QW];
+    uint64_t top[QW], tau[QW];
+#pragma unroll
+    for (int jq = 0; jq < QW; ++jq) {
+        top[jq] = KEY_NONE;
+        tau[jq] = KEY_NONE;
+        const int qi = __builtin_amdgcn_readfirstlane(a.inv_q[pair0 + (jq < nqw ? wave * QW + jq : 0)]);
+        qs[jq] = (const_f32p)(a.qpad + (long long)qi * a.d4p * 4);
+    }
+
+    const float4 *corpus4 = reinterpret_cast<const float4 *>(a.corpus);
+    const long long stride4 = a.row_stride >> 2;
+    const int d4 = a.d4p;
+    const int nkb = (d4 + KB - 1) / KB;
+    const int ntiles = (nrows + 63) >> 6;
+    const int nstages = ntiles * nkb;
+    // staging map: thread -> chunk c = tid & 31 of rows (tid >> 5) + (NT/32)*i (a wave-instruction = 2 rows = 1 KiB)
+    const int sc = tid & 31, sr = tid >> 5;
+    float4 stg[SPT];
+    auto stage_load = [&](int s) {
+        const int tl = s / nkb, kb = s - tl * nkb;
+        const int gc = kb * KB + sc;
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) {
+            const int r = tl * 64 + sr + (NT / 32) * i;
+            stg[i] = (r < nrows && gc < d4) ? corpus4[(long long)(row0 + r) * stride4 + gc] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    float acc[QW];
+    int32_t mygid = -1;
+    float myinv = 0.0f;
+    bool valid = false;
+    stage_load(0);
+    for (int s = 0; s < nstages; ++s) {
+        const int tl = s / nkb, kb = s - tl * nkb;
+        __syncthreads();  // everyone has finished reading the previous stage
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) tile[(sr + (NT / 32) * i) * RS + sc] = stg[i];
+        __syncthreads();
+        if (s + 1 < nstages) stage_load(s + 1);  // in flight while this stage is computed
+        if (kb == 0) {
+            valid = tl * 64 + lane < nrows;
+            const int prow = row0 + tl * 64 + (valid ? lane : 0);
+            mygid = valid ? a.gid[prow] : -1;
+            if (METRIC == NLSH_METRIC_COSINE) myinv = valid ? a.inv_norm[prow] : 0.0f;
+#pragma unroll
+            for (int jq = 0; jq < QW; ++jq) acc[jq] = 0.0f;
+        }
+        if (nqw > 0) {
+            const int nchunk = min(KB, d4 - kb * KB);
+            const_f32p qk[QW];
+#pragma unroll
+            for (int jq = 0; jq < QW; ++jq) qk[jq] = qs[jq] + kb * KB * 4;
+            if (nqw == QW) tile_accumulate<METRIC, QW, true>(tile + lane * RS, nchunk, qk, nqw, acc);
+            else tile_accumulate<METRIC, QW, false>(tile + lane * RS, nchunk, qk, nqw, acc);
+            if (kb == nkb - 1) {  // tile end: lane = row -> one candidate per lane and query
+#pragma unroll
+                for (int jq = 0; jq < QW; ++jq) {
+                    if (jq < nqw) {
+                        const float dist = finish_distance<METRIC>(acc[jq], myinv);
+                        const uint64_t key = valid ? make_key(dist, mygid) : KEY_NONE;
+                        topk_offer(top[jq], tau[jq], key, a.k, lane);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int jq = 0; jq < QW; ++jq)
+        if (jq < nqw && lane < a.k) a.partial[((long long)t * (QW * NW) + wave * QW + jq) * a.k + lane] = top[jq];
+}
+
 __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
     const int lane = threadIdx.x & 63;
     const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -267,10 +442,15 @@ __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
     store_topk(a.out_dist, a.out_idx, a.out_keys, q, a.k, top, lane);
 }
 
+#ifndef NLSH_TILED_QB
+#define NLSH_TILED_QB 16
+#endif
+constexpr int TILED_QB = NLSH_TILED_QB;  // queries per task of the tiled schedule (4 per wave)
+
 struct BWs {
-    size_t pbkt, pairpos, inv_q, bcount, pairoff, taskoff, counters, task, partial, total;
+    size_t pbkt, pairpos, inv_q, bcount, pairoff, taskoff, counters, task, partial, qpad, total;
 };
-static void blayout(long long Q, int P, int k, long long max_tasks, long long nb, BWs *w) {
+static void blayout(long long Q, int P, int k, long long max_tasks, long long nb, int d, bool tiled, BWs *w) {
     size_t o = 0;
     const size_t qp = (size_t)Q * P * 4, nb4 = (size_t)(nb > 0 ? nb : 1) * 4;
     w->pbkt = o;     o += ws_align(qp);
@@ -281,14 +461,16 @@ static void blayout(long long Q, int P, int k, long long max_tasks, long long nb
     w->taskoff = o;  o += ws_align(nb4);
     w->counters = o; o += ws_align(16);
     w->task = o;     o += ws_align((size_t)max_tasks * sizeof(int4));
-    w->partial = o;  o += ws_align((size_t)max_tasks * 8 * k * 8);
+    w->partial = o;  o += ws_align((size_t)max_tasks * (tiled ? TILED_QB : 8) * k * 8);
+    w->qpad = o;     o += tiled ? ws_align((size_t)Q * ((d + 3) / 4) * 16) : 0;
     w->total = o;
 }
 
-size_t bucket_scan_workspace(long long Q, int P, int k, long long max_tasks, long long n_buckets) {
-    BWs w;
-    blayout(Q, P, k, max_tasks, n_buckets, &w);
-    return w.total;
+size_t bucket_scan_workspace(long long Q, int P, int k, long long max_tasks, long long n_buckets, int d) {
+    BWs w, wt;
+    blayout(Q, P, k, max_tasks, n_buckets, d, false, &w);
+    blayout(Q, P, k, max_tasks, n_buckets, d, true, &wt);
+    return w.total > wt.total ? w.total : wt.total;
 }
 
 template <int METRIC>
@@ -302,13 +484,14 @@ static void launch_bscan2(const BArgs &a, int d4, unsigned grid, hipStream_t s) 
 
 int bucket_scan_run(const BucketScanCall &c) {
     BWs w;
-    blayout(c.Q, c.P, c.k, c.max_tasks, c.nb, &w);
+    blayout(c.Q, c.P, c.k, c.max_tasks, c.nb, c.d, c.tiled != 0, &w);
     NLSH_REQUIRE(c.workspace_bytes >= w.total, NLSH_E_WORKSPACE, "scan_topk(bucket-major): workspace %zu < %zu", c.workspace_bytes, w.total);
     const int d4 = (c.d + 3) / 4;
     BArgs a;
     a.corpus = c.corpus; a.row_stride = c.row_stride; a.d = c.d; a.gid = c.gid; a.uniq = c.uniq; a.offsets = c.offsets; a.nb = c.nb;
     a.inv_norm = c.inv_norm; a.queries = c.queries; a.q_stride = c.q_stride; a.Q = c.Q; a.qkeys = c.qkeys; a.nkeys = c.nkeys;
-    a.P = c.P; a.k = c.k; a.seg = c.seg; a.QB = d4 <= 64 ? 8 : (d4 <= 128 ? 4 : 2);
+    a.P = c.P; a.k = c.k; a.seg = c.seg; a.QB = c.tiled ? TILED_QB : (d4 <= 64 ? 8 : (d4 <= 128 ? 4 : 2));
+    a.qpad = (float *)((char *)c.workspace + w.qpad); a.d4p = d4;
     a.out_dist = c.out_dist; a.out_idx = c.out_idx; a.out_keys = c.out_keys; a.out_ncand = c.out_ncand; a.status = c.status;
     char *base = (char *)c.workspace;
     a.pbkt = (int32_t *)(base + w.pbkt); a.pairpos = (int32_t *)(base + w.pairpos); a.inv_q = (int32_t *)(base + w.inv_q);
@@ -325,11 +508,19 @@ int bucket_scan_run(const BucketScanCall &c) {
     hipLaunchKernelGGL(bplan_kernel, dim3(gp), dim3(256), 0, s, a);
     if (c.nb > 0) hipLaunchKernelGGL(bscan_kernel, dim3((unsigned)((c.nb + 255) / 256)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(bscatter_kernel, dim3(gp), dim3(256), 0, s, a);
+    if (c.tiled) hipLaunchKernelGGL(bprep_kernel, dim3((unsigned)c.Q), dim3(64), 0, s, a, c.metric);
     if (c.max_tasks > 0) {
-        const unsigned grid = (unsigned)((c.max_tasks + 3) / 4);
         if (c.ev_begin) NLSH_CHECK_HIP(hipEventRecord((hipEvent_t)c.ev_begin, s));
-        if (c.metric == NLSH_METRIC_L2_EPS) launch_bscan2<NLSH_METRIC_L2_EPS>(a, d4, grid, s);
-        else launch_bscan2<NLSH_METRIC_COSINE>(a, d4, grid, s);
+        if (c.tiled) {
+            const unsigned grid = (unsigned)c.max_tasks;  // one workgroup per task
+            // QW = 4 queries per wave (SGPR budget: two chunks x QW x 4 scalar values in flight), NW = 4 waves
+            if (c.metric == NLSH_METRIC_L2_EPS) hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_L2_EPS, 4, TILED_QB / 4>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
+            else hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_COSINE, 4, TILED_QB / 4>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
+        } else {
+            const unsigned grid = (unsigned)((c.max_tasks + 3) / 4);  // one wavefront per task
+            if (c.metric == NLSH_METRIC_L2_EPS) launch_bscan2<NLSH_METRIC_L2_EPS>(a, d4, grid, s);
+            else launch_bscan2<NLSH_METRIC_COSINE>(a, d4, grid, s);
+        }
         if (c.ev_end) NLSH_CHECK_HIP(hipEventRecord((hipEvent_t)c.ev_end, s));
     }
     hipLaunchKernelGGL(bmerge_kernel, dim3((unsigned)((c.Q + 3) / 4)), dim3(256), 0, s, a);

@@ -260,11 +260,11 @@ static void launch_scan(const ScanArgs &a, int d4, unsigned grid, hipStream_t s)
 
 using namespace nlsh;
 
-extern "C" size_t nlsh_scan_workspace(int64_t Q, int P, int k, int64_t max_tasks, int64_t n_buckets) {
-    if (Q < 0 || P < 1 || k < 1 || max_tasks < 0 || n_buckets < 0) { set_error("scan_workspace: bad sizes"); return 0; }
+extern "C" size_t nlsh_scan_workspace(int64_t Q, int P, int k, int64_t max_tasks, int64_t n_buckets, int d) {
+    if (Q < 0 || P < 1 || k < 1 || max_tasks < 0 || n_buckets < 0 || d < 1) { set_error("scan_workspace: bad sizes"); return 0; }
     ScanWs w;
     scan_layout(Q, P, k, max_tasks, &w);
-    const size_t b = bucket_scan_workspace(Q, P, k, max_tasks, n_buckets);
+    const size_t b = bucket_scan_workspace(Q, P, k, max_tasks, n_buckets, d);
     return w.total > b ? w.total : b;
 }
 
@@ -279,7 +279,8 @@ extern "C" int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, in
     NLSH_REQUIRE(k >= 1 && k <= NLSH_MAX_K, NLSH_E_UNSUPPORTED, "scan_topk: k=%d not in [1,%d]", k, NLSH_MAX_K);
     NLSH_REQUIRE(P >= 1 && P <= NLSH_MAX_PROBES, NLSH_E_UNSUPPORTED, "scan_topk: P=%d not in [1,%d]", P, NLSH_MAX_PROBES);
     NLSH_REQUIRE(metric == NLSH_METRIC_L2_EPS || metric == NLSH_METRIC_COSINE, NLSH_E_INVALID, "scan_topk: metric=%d", metric);
-    NLSH_REQUIRE(algo == NLSH_SCAN_QUERY_MAJOR || algo == NLSH_SCAN_BUCKET_MAJOR, NLSH_E_INVALID, "scan_topk: algo=%d", algo);
+    NLSH_REQUIRE(algo == NLSH_SCAN_QUERY_MAJOR || algo == NLSH_SCAN_BUCKET_MAJOR || algo == NLSH_SCAN_BUCKET_TILED, NLSH_E_INVALID,
+                 "scan_topk: algo=%d", algo);
     NLSH_REQUIRE(n_buckets >= 0 && max_tasks >= 0 && seg_rows >= 0, NLSH_E_INVALID, "scan_topk: negative size");
     if (Q == 0) return NLSH_OK;
     NLSH_REQUIRE(queries && qkeys && nkeys && out_dist && out_idx && out_ncand && status && workspace, NLSH_E_INVALID, "scan_topk: null pointer");
@@ -292,10 +293,10 @@ extern "C" int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, in
     seg_rows = (seg_rows + 63) / 64 * 64;
     hipStream_t s = (hipStream_t)stream;
 
-    if (algo == NLSH_SCAN_BUCKET_MAJOR) {
+    if (algo != NLSH_SCAN_QUERY_MAJOR) {
         BucketScanCall c = {corpus_sorted, row_stride, d, gid, uniq_keys, offsets, n_buckets, inv_norm, queries, q_stride, Q,
                             qkeys, nkeys, P, k, metric, seg_rows, out_dist, out_idx, out_keys, out_ncand, status, workspace,
-                            workspace_bytes, max_tasks, ev_scan_begin, ev_scan_end, s};
+                            workspace_bytes, max_tasks, ev_scan_begin, ev_scan_end, s, algo == NLSH_SCAN_BUCKET_TILED};
         return bucket_scan_run(c);
     }
 

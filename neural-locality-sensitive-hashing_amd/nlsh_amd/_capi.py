@@ -15,7 +15,7 @@ OK, E_INVALID, E_UNSUPPORTED, E_HIP, E_WORKSPACE = 0, -1, -2, -3, -4
 ACT_SIGMOID, ACT_TANH = 0, 1
 KEY_REF_INT16, KEY_FULL = 0, 1
 METRIC_L2_EPS, METRIC_COSINE = 0, 1
-SCAN_QUERY_MAJOR, SCAN_BUCKET_MAJOR = 0, 1
+SCAN_QUERY_MAJOR, SCAN_BUCKET_MAJOR, SCAN_BUCKET_TILED = 0, 1, 2
 MAX_LAYERS, MAX_HASH_BITS, MAX_PROBES, MAX_K, MAX_DIM, MAX_WIDTH = 8, 32, 64, 64, 1024, 632
 
 # every symbol include/nlsh_hip.h declares (tests/test_capi_symbols.py checks the header against this)
@@ -71,7 +71,7 @@ def lib():
     L.nlsh_gather_rows.restype = i32
     L.nlsh_gather_rows.argtypes = [vp, i64, i32, vp, i64, vp, i64, vp, vp, ctypes.c_int32, vp]
     L.nlsh_scan_workspace.restype = sz
-    L.nlsh_scan_workspace.argtypes = [i64, i32, i32, i64, i64]
+    L.nlsh_scan_workspace.argtypes = [i64, i32, i32, i64, i64, i32]
     L.nlsh_scan_topk.restype = i32
     L.nlsh_scan_topk.argtypes = [vp, i64, i32, vp, vp, vp, ctypes.c_int32, vp, vp, i64, i64, vp, vp, i32, i32, i32, i32, i32,
                                  vp, vp, vp, vp, vp, vp, sz, i64, vp, vp, vp]

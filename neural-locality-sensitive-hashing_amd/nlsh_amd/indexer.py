@@ -167,14 +167,16 @@ class Indexer:
         """Bucket-major pays when a corpus row is a candidate of several queries of the batch:
         expected (query, probe) pairs per row ~ Q * P * E[bucket size of a row] / N."""
         if self.algo is not None:
-            return _capi.SCAN_BUCKET_MAJOR if self.algo == "bucket" else _capi.SCAN_QUERY_MAJOR
+            return {"query": _capi.SCAN_QUERY_MAJOR, "bucket": _capi.SCAN_BUCKET_MAJOR, "tiled": _capi.SCAN_BUCKET_TILED}[self.algo]
         n = max(float(self.bucket_sizes.sum()), 1.0)
         reuse = Q * P * self._size_biased_bucket() / n
-        return _capi.SCAN_BUCKET_MAJOR if reuse >= 4.0 else _capi.SCAN_QUERY_MAJOR
+        return _capi.SCAN_BUCKET_TILED if reuse >= 8.0 else (_capi.SCAN_BUCKET_MAJOR if reuse >= 3.0 else _capi.SCAN_QUERY_MAJOR)
 
     def _estimate_tasks(self, Q, P, seg, algo):
         biased = self._size_biased_bucket()
-        if algo == _capi.SCAN_BUCKET_MAJOR:
+        if algo == _capi.SCAN_BUCKET_TILED:
+            est = Q * min(P, 4) * (1.0 / 16 + biased / seg / 16) + self.n_buckets
+        elif algo == _capi.SCAN_BUCKET_MAJOR:
             est = Q * min(P, 4) * (1.0 / 4 + biased / seg / 4) + self.n_buckets
         else:
             est = Q * (1.0 + min(P, 4) * biased / seg)
@@ -209,7 +211,7 @@ class Indexer:
             self._max_tasks[algo] = self._estimate_tasks(Q, P, seg, algo)
         while True:
             max_tasks = self._max_tasks[algo]
-            ws_bytes = L.nlsh_scan_workspace(Q, P, k, max_tasks, self.n_buckets)
+            ws_bytes = L.nlsh_scan_workspace(Q, P, k, max_tasks, self.n_buckets, d)
             if self._ws is None or self._ws.numel() < ws_bytes or self._ws.device != dev:
                 self._ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
             _capi.check(L.nlsh_scan_topk(

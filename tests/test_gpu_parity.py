@@ -159,7 +159,7 @@ def test_build_index_reference_vector_and_random():
 
 
 # ----------------------------------------------------------------------------- a8-a10 scan on injected keys
-@pytest.mark.parametrize("algo", ["query", "bucket"])
+@pytest.mark.parametrize("algo", ["query", "bucket", "tiled"])
 @pytest.mark.parametrize("name", ["l2_small", "cos_small", "l2_k3"])
 def test_scan_golden_injected_keys(name, algo):
     from nlsh_amd.data import Glove, SIFT
@@ -206,7 +206,7 @@ SCAN_CASES = [
 ]
 
 
-@pytest.mark.parametrize("algo", ["query", "bucket"])
+@pytest.mark.parametrize("algo", ["query", "bucket", "tiled"])
 @pytest.mark.parametrize("metric,d,N,Q,H,k,seg,P", SCAN_CASES)
 def test_scan_vs_oracle_shapes(metric, d, N, Q, H, k, seg, P, algo):
     from nlsh_amd.data import Glove, SIFT
@@ -358,3 +358,24 @@ def test_both_schedules_are_bit_identical():
             out.append(ix.query_tensors(dev(queries), k=10, hash_times=8, seed=3, want_keys=True))
         for a, b in zip(out[0], out[1]):
             assert torch.equal(a, b)
+
+
+def test_tiled_schedule_l2_distances_bit_exact_vs_oracle():
+    """The LDS-tiled schedule sums each distance as a k-ascending fmaf chain: bit-identical to the
+    oracle's scalar loop (oracle_l2), so ids AND distances must equal the oracle's exactly."""
+    from nlsh_amd.data import SIFT
+    from nlsh_amd.indexer import Indexer
+    for d, seg in ((128, 128), (100, 0), (200, 64), (50, 0)):
+        corpus, queries = synth.sift_like(30000, d, seed=15), synth.sift_like(400, d, seed=16)
+        corpus[200:260] = corpus[20000:20060]                       # exact ties -> id tie-break
+        Ws, bs = synth.make_weights([d, 64, 6], seed=15)
+        hashing = make_hashing(d, (64,), 6, Ws, bs)
+        ix = Indexer(hashing, dev(corpus), SIFT.distance, algo="tiled", seg_rows=seg)
+        keys, nkeys = ix.hash_device(dev(queries), hash_times=6, seed=5)
+        dist, idx, nc, _ = ix.scan_tensors(dev(queries), keys, nkeys, k=10)
+        perm, uniq, offs = oracle.build_csr(ix.corpus_keys.cpu().numpy().astype(np.int64))
+        od, oi, onc = oracle.query_batch(corpus, perm, uniq, offs, queries, keys.cpu().numpy().astype(np.int64),
+                                         nkeys.cpu().numpy(), 10, "l2")
+        assert np.array_equal(nc.cpu().numpy(), onc)
+        assert np.array_equal(idx.cpu().numpy(), oi)
+        assert np.array_equal(dist.cpu().numpy().view(np.uint32), od.view(np.uint32))

@@ -29,7 +29,7 @@ def test_capi_library_exports_every_declared_symbol():
     assert lib.nlsh_encoder_packed_floats(3, _capi.int_array([128, 256, 256, 33])) == -1
     assert b"hash_size" in lib.nlsh_last_error()
     assert lib.nlsh_encoder_packed_floats(2, _capi.int_array([128, 700, 16])) == -1       # 128 ok, 700 too wide
-    assert lib.nlsh_scan_workspace(10, 4, 10, 100, 50) > 0
+    assert lib.nlsh_scan_workspace(10, 4, 10, 100, 50, 128) > 0
 
 
 def test_product_never_references_the_oracle():
