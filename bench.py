@@ -162,6 +162,17 @@ def main():
         ids_api, nc_api = indexer.query(queries, k=k, hash_times=P)
         api_qps = Q / (time.perf_counter() - t0)
 
+    # HBM traffic per launch: PMC numbers cannot be collected from inside the process; they come from
+    # the committed rocprofv3 --pmc passes of this round (profiles/traffic_r01.json) when the workload matches.
+    traffic = None
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
+        w = tr["workload"]
+        if (w["N"], w["d"], w["Q"], w["H"], w["hash_times"]) == (N, d, Q, H, P) and world == 1 and "learned" in hash_desc:
+            traffic = tr["traffic_bytes_per_launch"].get(str(indexer.last_algo))
+    except (OSError, KeyError, ValueError):
+        pass
+
     result = None
     if rank == 0:
         gt = brute_force_topk(queries, torch.from_numpy(corpus_h).to(dev), k, "l2").cpu().numpy()
@@ -183,7 +194,8 @@ def main():
                        "bucket_max": stats["max"], "mean_candidates_per_query": mean_c,
                        "index_build_s": build_s, "api_list_qps": api_qps},
             "roofline": {"bound": "hbm", "kernel": {0: "scan_kernel<32,1,L2> (query-major)", 1: "bscan2_kernel<32,1,L2,8> (bucket-major)", 2: "bscan3_kernel<L2> (bucket-major, LDS-tiled)"}[indexer.last_algo], "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "note": "achieved = ALGORITHMIC bytes (4*d*sum C_q) / kernel time; the bucket-major schedules fetch each row once per query GROUP, so frac > 1 means HBM traffic (see traffic, bytes/launch from PMC) is far below the algorithmic bytes and the kernel is fp32-VALU-bound",
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms,
                          "sum_candidates_per_launch": sum_c_local, "tasks_per_launch": n_tasks},
         }
