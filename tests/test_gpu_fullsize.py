@@ -1,0 +1,117 @@
+"""Full-size (BASELINE.json configs[1]: 1M x 128-d, 10k queries, 16-bit learned hash) property tests.
+The oracle cannot brute-force this size in seconds, so parity is checked through size-independent
+properties plus an oracle check on a slice of the queries."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import dev, make_hashing
+from nlsh_amd import synth
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CKPT = os.path.join(ROOT, "neural-locality-sensitive-hashing_amd", "checkpoints", "sift1m_manifold_h16.npz")
+
+
+@pytest.fixture(scope="module")
+def sift1m():
+    from nlsh_amd.data import SIFT
+    from nlsh_amd.indexer import Indexer
+    N, Q, d = 1_000_000, 10_000, 128
+    corpus, mean, std = synth.standardise(synth.sift_manifold(N, d, seed=synth.SEED_DATA))
+    queries, _, _ = synth.standardise(synth.sift_manifold(Q, d, seed=synth.SEED_QUERY), mean, std)
+    arrs = np.load(CKPT)
+    Ws, bs = [arrs[f"W{i}"] for i in range(3)], [arrs[f"b{i}"] for i in range(3)]
+    hashing = make_hashing(d, (256, 256), 16, Ws, bs)
+    cg, qg = dev(corpus), dev(queries)
+    indexers = {a: Indexer(hashing, cg, SIFT.distance, algo=a) for a in ("query", "bucket", "tiled")}
+    return dict(corpus=corpus, queries=queries, cg=cg, qg=qg, Ws=Ws, bs=bs, hashing=hashing, indexers=indexers)
+
+
+def test_index_is_a_permutation_grouped_by_key(sift1m):
+    ix = sift1m["indexers"]["tiled"]
+    perm = ix.perm.long()
+    N = perm.numel()
+    assert torch.equal(torch.sort(perm).values, torch.arange(N, device=perm.device))          # a permutation
+    sk = ix.corpus_keys[perm]
+    assert bool((sk[1:] >= sk[:-1]).all())                                                     # buckets ascending
+    same = sk[1:] == sk[:-1]
+    assert bool((perm[1:][same] > perm[:-1][same]).all())                                      # rows ascending inside
+    assert torch.equal(ix.corpus_sorted[:, :128], sift1m["cg"][perm])                          # gather is exact
+    assert int(ix.offsets[-1]) == N and ix.n_buckets == int(torch.unique(ix.corpus_keys).numel())
+
+
+def test_results_properties_and_schedule_agreement(sift1m):
+    qg, cg = sift1m["qg"], sift1m["cg"]
+    k, P, seed = 10, 10, 4242
+    out = {}
+    for name, ix in sift1m["indexers"].items():
+        keys, nkeys = ix.hash_device(qg, hash_times=P, seed=seed)
+        out[name] = (keys, nkeys) + ix.scan_tensors(qg, keys, nkeys, k=k)[:3]
+    keys, nkeys, dist, idx, nc = out["tiled"]
+    # same keys for every schedule (hashing is schedule-independent); F6: last partial batch single-probe
+    assert torch.equal(out["query"][0], keys) and torch.equal(out["query"][1], nkeys)
+    assert int(nkeys[8192:].max()) == 1 and int(nkeys[:8192].max()) > 1
+    # n_candidates = sum of the sizes of the probed buckets (independent recomputation with torch ops)
+    ix = sift1m["indexers"]["tiled"]
+    pos = torch.searchsorted(ix.uniq_keys, keys.clamp(min=int(ix.uniq_keys.min()), max=int(ix.uniq_keys.max())))
+    pos = pos.clamp(max=ix.n_buckets - 1)
+    hit = ix.uniq_keys[pos] == keys
+    sizes = (ix.offsets[1:] - ix.offsets[:-1])[pos] * hit
+    valid = torch.arange(keys.shape[1], device=keys.device)[None, :] < nkeys[:, None]
+    assert torch.equal((sizes * valid).sum(1).int(), nc)
+    for name in ("query", "bucket"):
+        assert torch.equal(out[name][4], nc)
+    # every returned id is a real candidate: its corpus key is one of the query's keys
+    ok = idx >= 0
+    ck = ix.corpus_keys[idx.clamp(min=0).long()]
+    member = ((ck[:, :, None] == keys[:, None, :]) & valid[:, None, :]).any(-1)
+    assert bool((member | ~ok).all())
+    # ascending, no duplicates, distances equal a recomputation with stock torch ops
+    assert bool((dist[:, 1:] >= dist[:, :-1]).all())
+    srt = torch.sort(idx, dim=1).values
+    assert bool(((srt[:, 1:] != srt[:, :-1]) | (srt[:, 1:] < 0)).all())
+    ref = torch.nn.functional.pairwise_distance(qg[:, None, :].expand(-1, k, -1).reshape(-1, 128),
+                                                cg[idx.clamp(min=0).long().reshape(-1)]).reshape(-1, k)
+    assert bool(((dist - ref).abs() <= 2e-5 * ref.clamp(min=1.0))[ok].all())
+    # schedules: query-major == bucket-major bitwise; tiled differs only by fp32 summation order
+    assert torch.equal(out["query"][2], out["bucket"][2]) and torch.equal(out["query"][3], out["bucket"][3])
+    dq, iq = out["query"][2], out["query"][3]
+    assert float((idx == iq).float().mean()) > 0.999
+    assert bool(((dist - dq).abs() <= 2e-5 * dq.clamp(min=1.0))[ok & (iq >= 0)].all())
+    # idempotence
+    again = ix.scan_tensors(qg, keys, nkeys, k=k)
+    assert torch.equal(again[0], dist) and torch.equal(again[1], idx)
+
+
+def test_oracle_on_a_query_slice(sift1m):
+    """First 64 queries of the full-size index against the CPU oracle (bit-exact for the tiled schedule)."""
+    ix = sift1m["indexers"]["tiled"]
+    qg = sift1m["qg"][:64]
+    keys, nkeys = ix._hashing.hash_device(qg, n=10, seed=77)
+    dist, idx, nc, _ = ix.scan_tensors(qg, keys, nkeys, k=10)
+    perm, uniq, offs = oracle.build_csr(ix.corpus_keys.cpu().numpy().astype(np.int64))
+    od, oi, onc = oracle.query_batch(sift1m["corpus"], perm, uniq, offs, sift1m["queries"][:64],
+                                     keys.cpu().numpy().astype(np.int64), nkeys.cpu().numpy(), 10, "l2")
+    assert np.array_equal(nc.cpu().numpy(), onc)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.array_equal(dist.cpu().numpy().view(np.uint32), od.view(np.uint32))
+    # corpus keys themselves: oracle forward (k-ordered fmaf chain) on a 4096-row slice is bit-exact
+    z = oracle.mlp_forward(sift1m["corpus"][:4096], sift1m["Ws"], sift1m["bs"])
+    _, p01 = oracle.head_probs(z)
+    ko, _ = oracle.row_keys(p01, 1, "ref_int16")
+    assert np.array_equal(ko[:, 0], ix.corpus_keys[:4096].cpu().numpy())
+
+
+def test_recall_matches_bench_claim(sift1m):
+    from nlsh_amd.data import brute_force_topk
+    from nlsh_amd.metrics import calculate_recall
+    ix = sift1m["indexers"]["tiled"]
+    gt = brute_force_topk(sift1m["qg"], sift1m["cg"], 10, "l2").cpu().numpy()
+    ids, nc = ix.query(sift1m["qg"], k=10, hash_times=10)
+    rec = calculate_recall(list(gt), ids, np.mean)
+    assert 0.70 < rec < 0.78, rec                       # bench.py reports 0.733 with its probe seed
+    assert 1500 < np.mean(nc) < 3500
