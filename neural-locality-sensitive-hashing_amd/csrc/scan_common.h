@@ -35,10 +35,26 @@ __device__ __forceinline__ float group_sum(float x) {
     return x;
 }
 
+// 64-bit value of lane `src` (wave-uniform index) as a wave-uniform value: two v_readlane_b32,
+// no LDS round trip (a generic __shfl compiles to ds_bpermute).
+__device__ __forceinline__ uint64_t read_lane64(uint64_t v, int src) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// value of lane-1 (lane 0 keeps its own): DPP wave_shr:1, two v_mov_b32_dpp
+__device__ __forceinline__ uint64_t lane_shift_up64(uint64_t v) {
+    const int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
+    const uint32_t slo = (uint32_t)__builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xF, 0xF, false);
+    const uint32_t shi = (uint32_t)__builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xF, 0xF, false);
+    return ((uint64_t)shi << 32) | slo;
+}
+
 // best-64 list, sorted ascending across lanes; insert one wave-uniform key
 __device__ __forceinline__ void topk_insert(uint64_t &top, uint64_t c, int lane) {
     const int posn = __popcll(__ballot(top < c));
-    const uint64_t up = __shfl_up(top, 1);
+    const uint64_t up = lane_shift_up64(top);
     top = lane < posn ? top : (lane == posn ? c : up);
 }
 
@@ -48,10 +64,10 @@ __device__ __forceinline__ void topk_offer(uint64_t &top, uint64_t &tau, uint64_
     while (m) {
         const int src = __ffsll((long long)m) - 1;
         m &= m - 1;
-        const uint64_t c = __shfl(key, src);
+        const uint64_t c = read_lane64(key, src);
         if (c < tau) {
             topk_insert(top, c, lane);
-            tau = __shfl(top, k - 1);
+            tau = read_lane64(top, k - 1);
         }
     }
 }
