@@ -45,7 +45,9 @@ struct BArgs {
     int4 *task;
     uint64_t *partial;
     long long max_tasks;
-    float *qpad;  // tiled variant: queries padded to d4p*4 floats (L2: pad = -eps; cosine: pre-normalised, pad = 0)
+    const float *qpad;  // tiled variant: queries padded to d4p*4 floats (L2: pad = -eps; cosine: pre-normalised, pad = 0)
+    float *qpad_w;      // same buffer, writable (bprep); qpad aliases `queries` when no padding/normalisation is needed
+    long long qpad_stride;
     int d4p;
 };
 
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(64) void bprep_kernel(BArgs a, int metric) {
     const long long q = blockIdx.x;
     const int lane = threadIdx.x;
     const float *qp = a.queries + q * a.q_stride;
-    float *dst = a.qpad + q * (long long)a.d4p * 4;
+    float *dst = a.qpad_w + q * a.qpad_stride;
     const int n = a.d4p * 4;
     if (metric == NLSH_METRIC_L2_EPS) {
         for (int e = lane; e < n; e += 64) dst[e] = e < a.d ? qp[e] : -1e-6f;  // (q - 0) + eps == 0 on padding
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
         top[jq] = KEY_NONE;
         tau[jq] = KEY_NONE;
         const int qi = __builtin_amdgcn_readfirstlane(a.inv_q[pair0 + (jq < nqw ? wave * QW + jq : 0)]);
-        qs[jq] = (const_f32p)(a.qpad + (long long)qi * a.d4p * 4);
+        qs[jq] = (const_f32p)(a.qpad + (long long)qi * a.qpad_stride);
     }
 
     const float4 *corpus4 = reinterpret_cast<const float4 *>(a.corpus);
@@ -424,17 +426,27 @@ __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
     int nk = __builtin_amdgcn_readfirstlane(a.nkeys[q]);
     nk = nk < 0 ? 0 : (nk > a.P ? a.P : nk);
     uint64_t top = KEY_NONE, tau = KEY_NONE;
+    // lane p resolves probe p (all the dependent index loads of the nk probes overlap), then the
+    // wave walks the partial lists with the per-probe values broadcast by v_readlane
+    int ns_l = 0, j_l = 0;
+    long long t0_l = 0;
+    if (lane < nk) {
+        const int b = a.pbkt[q * a.P + lane];
+        if (b >= 0) {
+            const int rel = a.pairpos[q * a.P + lane] - a.pairoff[b];
+            const int gi = rel / a.QB;
+            j_l = rel - gi * a.QB;
+            ns_l = (a.offsets[b + 1] - a.offsets[b] + a.seg - 1) / a.seg;
+            t0_l = (long long)a.taskoff[b] + (long long)gi * ns_l;
+        }
+    }
     for (int p = 0; p < nk; ++p) {
-        const int b = __builtin_amdgcn_readfirstlane(a.pbkt[q * a.P + p]);
-        if (b < 0) continue;
-        const int rel = __builtin_amdgcn_readfirstlane(a.pairpos[q * a.P + p]) - __builtin_amdgcn_readfirstlane(a.pairoff[b]);
-        const int gi = rel / a.QB, j = rel - gi * a.QB;
-        const int s = __builtin_amdgcn_readfirstlane(a.offsets[b + 1]) - __builtin_amdgcn_readfirstlane(a.offsets[b]);
-        const int ns = (s + a.seg - 1) / a.seg;
-        const long long t0 = (long long)__builtin_amdgcn_readfirstlane(a.taskoff[b]) + (long long)gi * ns;
+        const int ns = __builtin_amdgcn_readlane(ns_l, p);
+        const int j = __builtin_amdgcn_readlane(j_l, p);
+        const long long t0 = (long long)read_lane64((uint64_t)t0_l, p);
         for (int si = 0; si < ns; ++si) {
             const long long t = t0 + si;
-            if (t >= a.max_tasks) break;  // overflow: status[1] set by bscan2
+            if (t >= a.max_tasks) break;  // overflow: status[1] set by the scan kernel
             const uint64_t key = lane < a.k ? a.partial[(t * a.QB + j) * a.k + lane] : KEY_NONE;
             topk_offer(top, tau, key, a.k, lane);
         }
@@ -491,7 +503,10 @@ int bucket_scan_run(const BucketScanCall &c) {
     a.corpus = c.corpus; a.row_stride = c.row_stride; a.d = c.d; a.gid = c.gid; a.uniq = c.uniq; a.offsets = c.offsets; a.nb = c.nb;
     a.inv_norm = c.inv_norm; a.queries = c.queries; a.q_stride = c.q_stride; a.Q = c.Q; a.qkeys = c.qkeys; a.nkeys = c.nkeys;
     a.P = c.P; a.k = c.k; a.seg = c.seg; a.QB = c.tiled ? TILED_QB : (d4 <= 64 ? 8 : (d4 <= 128 ? 4 : 2));
-    a.qpad = (float *)((char *)c.workspace + w.qpad); a.d4p = d4;
+    a.qpad_w = (float *)((char *)c.workspace + w.qpad); a.qpad = a.qpad_w; a.qpad_stride = (long long)d4 * 4; a.d4p = d4;
+    // L2 with d % 4 == 0 needs neither padding nor normalisation: read the caller's queries directly
+    const bool prep = c.tiled && !(c.metric == NLSH_METRIC_L2_EPS && (c.d & 3) == 0 && (c.q_stride & 3) == 0 && ((uintptr_t)c.queries & 15) == 0);
+    if (c.tiled && !prep) { a.qpad = c.queries; a.qpad_stride = c.q_stride; }
     a.out_dist = c.out_dist; a.out_idx = c.out_idx; a.out_keys = c.out_keys; a.out_ncand = c.out_ncand; a.status = c.status;
     char *base = (char *)c.workspace;
     a.pbkt = (int32_t *)(base + w.pbkt); a.pairpos = (int32_t *)(base + w.pairpos); a.inv_q = (int32_t *)(base + w.inv_q);
@@ -508,7 +523,7 @@ int bucket_scan_run(const BucketScanCall &c) {
     hipLaunchKernelGGL(bplan_kernel, dim3(gp), dim3(256), 0, s, a);
     if (c.nb > 0) hipLaunchKernelGGL(bscan_kernel, dim3((unsigned)((c.nb + 255) / 256)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(bscatter_kernel, dim3(gp), dim3(256), 0, s, a);
-    if (c.tiled) hipLaunchKernelGGL(bprep_kernel, dim3((unsigned)c.Q), dim3(64), 0, s, a, c.metric);
+    if (prep) hipLaunchKernelGGL(bprep_kernel, dim3((unsigned)c.Q), dim3(64), 0, s, a, c.metric);
     if (c.max_tasks > 0) {
         if (c.ev_begin) NLSH_CHECK_HIP(hipEventRecord((hipEvent_t)c.ev_begin, s));
         if (c.tiled) {
