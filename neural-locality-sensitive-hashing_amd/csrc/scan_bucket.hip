@@ -19,6 +19,10 @@
 // Results do not depend on slot/task order: every list is merged with the (distance, id) comparator.
 #include "scan_common.h"
 
+#ifndef NLSH_ABLATE
+#define NLSH_ABLATE 0  // diagnostic timing builds only: 1 no distance math, 2 no global loads, 3 no top-k, 4 no scalar loads
+#endif
+
 namespace nlsh {
 
 struct BArgs {
@@ -45,6 +49,7 @@ struct BArgs {
     int4 *task;
     uint64_t *partial;
     long long max_tasks;
+    unsigned long long *tauq;  // [Q] running upper bound of each query's k-th best key (atomicMin), KEY_NONE-initialised
     const float *qpad;  // tiled variant: queries padded to d4p*4 floats (L2: pad = -eps; cosine: pre-normalised, pad = 0)
     float *qpad_w;      // same buffer, writable (bprep); qpad aliases `queries` when no padding/normalisation is needed
     long long qpad_stride;
@@ -284,7 +289,7 @@ __device__ __forceinline__ void load_qchunk(QChunk<QW> &qc, const const_f32p (&q
     for (int jq = 0; jq < QW; ++jq)
         if (FULL || jq < nqw) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) qc.v[jq][e] = qs[jq][4 * c + e];  // one s_load_dwordx4 per query
+            for (int e = 0; e < 4; ++e) qc.v[jq][e] = NLSH_ABLATE == 4 ? (float)(c + e) : qs[jq][4 * c + e];  // one s_load_dwordx4 per query
         }
 }
 
@@ -305,32 +310,21 @@ __device__ __forceinline__ void apply_qchunk(const QChunk<QW> &qc, const float4 
     }
 }
 
-// Chunks are processed in pairs through two scalar register sets: the s_loads of chunk c+1 are
-// issued before chunk c is evaluated, so the scalar-cache latency hides under the VALU work.
-template <int METRIC, int QW, bool FULL>
-__device__ __forceinline__ void tile_accumulate(const float4 *lds_row, int nchunk, const const_f32p (&qs)[QW], int nqw, float (&acc)[QW]) {
-    QChunk<QW> qa, qb;
-    load_qchunk<QW, FULL>(qa, qs, nqw, 0);
-    for (int c = 0; c < nchunk; c += 2) {
-        const float4 rv0 = lds_row[c];
-        const bool has1 = c + 1 < nchunk;
-        const float4 rv1 = lds_row[has1 ? c + 1 : c];
-        load_qchunk<QW, FULL>(qb, qs, nqw, has1 ? c + 1 : c);
-        apply_qchunk<METRIC, QW, FULL>(qa, rv0, nqw, acc);
-        if (!has1) break;
-        load_qchunk<QW, FULL>(qa, qs, nqw, c + 2 < nchunk ? c + 2 : c);
-        apply_qchunk<METRIC, QW, FULL>(qb, rv1, nqw, acc);
-    }
-}
-
-// QW queries per wave, NW waves per workgroup: QW*NW queries per task.
-template <int METRIC, int QW, int NW>
+// QW queries per wave, NW waves per workgroup (QW*NW queries per task), TPS 64-row tiles per task.
+// k-blocks of KB chunks are the OUTER loop: one stage holds the KB-chunk slice of ALL 64*TPS rows of
+// the segment in LDS, so every scalar-loaded query chunk is applied to TPS row tiles (TPS x fewer
+// scalar loads and SALU per VALU than a tile-outer loop) and the accumulators of all tiles live in
+// registers until the last k-block.  Chunks go through two scalar register sets: the s_loads of
+// chunk c+1 are issued before chunk c is evaluated.
+template <int METRIC, int QW, int NW, int TPS>
 __global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
-    constexpr int NT = 64 * NW;         // threads per workgroup
-    constexpr int KB = 32;              // 16-byte chunks per k-block (128 floats)
-    constexpr int RS = KB + 1;          // LDS row stride in 16-byte slots (odd -> conflict-free ds_read_b128 down a column)
-    constexpr int SPT = 64 * KB / NT;   // staged 16-byte words per thread and stage
-    __shared__ float4 tile[64 * RS];
+    constexpr int NT = 64 * NW;              // threads per workgroup
+    constexpr int KB = 8;                    // 16-byte chunks per k-block (32 floats)
+    constexpr int RS = KB + 1;               // odd LDS row stride (16-byte slots) -> conflict-free column reads
+    constexpr int ROWS = 64 * TPS;
+    constexpr int SPT = ROWS * KB / NT;      // staged 16-byte words per thread and stage
+    constexpr int RPP = NT / KB;             // rows covered by one pass of the workgroup
+    __shared__ float4 tile[ROWS * RS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long t = blockIdx.x;
     long long ntasks = a.status[0];
@@ -343,80 +337,106 @@ __global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
     const int pair0 = __builtin_amdgcn_readfirstlane(desc.x);
     const int nq = __builtin_amdgcn_readfirstlane(desc.y);
     const int row0 = __builtin_amdgcn_readfirstlane(desc.z);
-    const int nrows = __builtin_amdgcn_readfirstlane(desc.w);
+    const int nrows = __builtin_amdgcn_readfirstlane(desc.w);  // <= ROWS (the host fixes seg = ROWS)
     int nqw = nq - wave * QW;
     nqw = __builtin_amdgcn_readfirstlane(nqw < 0 ? 0 : (nqw > QW ? QW : nqw));
 
     const_f32p qs[QW];
-    uint64_t top[QW], tau[QW];
+    int qid[QW];
 #pragma unroll
     for (int jq = 0; jq < QW; ++jq) {
-        top[jq] = KEY_NONE;
-        tau[jq] = KEY_NONE;
-        const int qi = __builtin_amdgcn_readfirstlane(a.inv_q[pair0 + (jq < nqw ? wave * QW + jq : 0)]);
-        qs[jq] = (const_f32p)(a.qpad + (long long)qi * a.qpad_stride);
+        qid[jq] = __builtin_amdgcn_readfirstlane(a.inv_q[pair0 + (jq < nqw ? wave * QW + jq : 0)]);
+        qs[jq] = (const_f32p)(a.qpad + (long long)qid[jq] * a.qpad_stride);
     }
 
     const float4 *corpus4 = reinterpret_cast<const float4 *>(a.corpus);
     const long long stride4 = a.row_stride >> 2;
     const int d4 = a.d4p;
     const int nkb = (d4 + KB - 1) / KB;
-    const int ntiles = (nrows + 63) >> 6;
-    const int nstages = ntiles * nkb;
-    // staging map: thread -> chunk c = tid & 31 of rows (tid >> 5) + (NT/32)*i (a wave-instruction = 2 rows = 1 KiB)
-    const int sc = tid & 31, sr = tid >> 5;
+    const int ntile = (nrows + 63) >> 6;
+    // staging map: KB threads cover 16*KB contiguous bytes of a row
+    const int sc = tid % KB, sr = tid / KB;
     float4 stg[SPT];
-    auto stage_load = [&](int s) {
-        const int tl = s / nkb, kb = s - tl * nkb;
+    auto stage_load = [&](int kb) {
         const int gc = kb * KB + sc;
 #pragma unroll
         for (int i = 0; i < SPT; ++i) {
-            const int r = tl * 64 + sr + (NT / 32) * i;
-            stg[i] = (r < nrows && gc < d4) ? corpus4[(long long)(row0 + r) * stride4 + gc] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int r = sr + RPP * i;
+            stg[i] = (NLSH_ABLATE != 2 && r < nrows && gc < d4) ? corpus4[(long long)(row0 + r) * stride4 + gc] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    float acc[QW];
-    int32_t mygid = -1;
-    float myinv = 0.0f;
-    bool valid = false;
+    float acc[TPS][QW];
+#pragma unroll
+    for (int tl = 0; tl < TPS; ++tl)
+#pragma unroll
+        for (int jq = 0; jq < QW; ++jq) acc[tl][jq] = 0.0f;
+
     stage_load(0);
-    for (int s = 0; s < nstages; ++s) {
-        const int tl = s / nkb, kb = s - tl * nkb;
-        __syncthreads();  // everyone has finished reading the previous stage
+    for (int kb = 0; kb < nkb; ++kb) {
+        __syncthreads();  // everyone has finished reading the previous k-block
 #pragma unroll
-        for (int i = 0; i < SPT; ++i) tile[(sr + (NT / 32) * i) * RS + sc] = stg[i];
+        for (int i = 0; i < SPT; ++i) tile[(sr + RPP * i) * RS + sc] = stg[i];
         __syncthreads();
-        if (s + 1 < nstages) stage_load(s + 1);  // in flight while this stage is computed
-        if (kb == 0) {
-            valid = tl * 64 + lane < nrows;
-            const int prow = row0 + tl * 64 + (valid ? lane : 0);
-            mygid = valid ? a.gid[prow] : -1;
-            if (METRIC == NLSH_METRIC_COSINE) myinv = valid ? a.inv_norm[prow] : 0.0f;
-#pragma unroll
-            for (int jq = 0; jq < QW; ++jq) acc[jq] = 0.0f;
-        }
-        if (nqw > 0) {
+        if (kb + 1 < nkb) stage_load(kb + 1);  // in flight while this k-block is computed
+        if (NLSH_ABLATE != 1 && nqw > 0) {
             const int nchunk = min(KB, d4 - kb * KB);
             const_f32p qk[QW];
 #pragma unroll
             for (int jq = 0; jq < QW; ++jq) qk[jq] = qs[jq] + kb * KB * 4;
-            if (nqw == QW) tile_accumulate<METRIC, QW, true>(tile + lane * RS, nchunk, qk, nqw, acc);
-            else tile_accumulate<METRIC, QW, false>(tile + lane * RS, nchunk, qk, nqw, acc);
-            if (kb == nkb - 1) {  // tile end: lane = row -> one candidate per lane and query
+            const float4 *col = tile + lane * RS;
+            QChunk<QW> qa, qb;
+            load_qchunk<QW, false>(qa, qk, nqw, 0);
+            for (int c = 0; c < nchunk; c += 2) {
+                const bool has1 = c + 1 < nchunk;
+                load_qchunk<QW, false>(qb, qk, nqw, has1 ? c + 1 : c);
 #pragma unroll
-                for (int jq = 0; jq < QW; ++jq) {
-                    if (jq < nqw) {
-                        const float dist = finish_distance<METRIC>(acc[jq], myinv);
-                        const uint64_t key = valid ? make_key(dist, mygid) : KEY_NONE;
-                        topk_offer(top[jq], tau[jq], key, a.k, lane);
-                    }
+                for (int tl = 0; tl < TPS; ++tl)
+                    if (tl < ntile) apply_qchunk<METRIC, QW, false>(qa, col[tl * 64 * RS + c], nqw, acc[tl]);
+                if (!has1) break;
+                load_qchunk<QW, false>(qa, qk, nqw, c + 2 < nchunk ? c + 2 : c);
+#pragma unroll
+                for (int tl = 0; tl < TPS; ++tl)
+                    if (tl < ntile) apply_qchunk<METRIC, QW, false>(qb, col[tl * 64 * RS + c + 1], nqw, acc[tl]);
+            }
+        }
+    }
+    if (nqw == 0) return;
+    // lane = row of each tile -> one candidate per lane, tile and query
+    // Lists of the same query in other tasks publish their k-th best key to tauq[q] (atomicMin): no
+    // candidate above it can reach the final top-k, so it pre-filters this list (fewer insertions).
+    // Which partial entries survive depends on timing; the merged result does not.
+    uint64_t top[QW], tau[QW];
+#pragma unroll
+    for (int jq = 0; jq < QW; ++jq) {
+        top[jq] = KEY_NONE;
+        tau[jq] = jq < nqw ? global_tau_load(a.tauq + qid[jq]) : KEY_NONE;
+    }
+#pragma unroll
+    for (int tl = 0; tl < TPS; ++tl) {
+        if (tl < ntile) {
+            const bool valid = tl * 64 + lane < nrows;
+            const int prow = row0 + tl * 64 + (valid ? lane : 0);
+            const int32_t mygid = valid ? a.gid[prow] : -1;
+            float myinv = 0.0f;
+            if (METRIC == NLSH_METRIC_COSINE) myinv = valid ? a.inv_norm[prow] : 0.0f;
+#pragma unroll
+            for (int jq = 0; jq < QW; ++jq) {
+                if (jq < nqw) {
+                    const float dist = finish_distance<METRIC>(acc[tl][jq], myinv);
+                    const uint64_t key = valid ? make_key(dist, mygid) : KEY_NONE;
+                    if (NLSH_ABLATE != 3) topk_offer(top[jq], tau[jq], key, a.k, lane);
+                    else top[jq] ^= key;
                 }
             }
         }
     }
 #pragma unroll
-    for (int jq = 0; jq < QW; ++jq)
-        if (jq < nqw && lane < a.k) a.partial[((long long)t * (QW * NW) + wave * QW + jq) * a.k + lane] = top[jq];
+    for (int jq = 0; jq < QW; ++jq) {
+        if (jq < nqw) {
+            if (lane < a.k) a.partial[((long long)t * (QW * NW) + wave * QW + jq) * a.k + lane] = top[jq];
+            global_tau_publish(a.tauq + qid[jq], top[jq], a.k, lane);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
@@ -458,9 +478,13 @@ __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
 #define NLSH_TILED_QB 16
 #endif
 constexpr int TILED_QB = NLSH_TILED_QB;  // queries per task of the tiled schedule (4 per wave)
+#ifndef NLSH_TILED_TPS
+#define NLSH_TILED_TPS 4
+#endif
+constexpr int TILED_TPS = NLSH_TILED_TPS;  // 64-row tiles per task of the tiled schedule (segment = 64*TPS rows)
 
 struct BWs {
-    size_t pbkt, pairpos, inv_q, bcount, pairoff, taskoff, counters, task, partial, qpad, total;
+    size_t pbkt, pairpos, inv_q, bcount, pairoff, taskoff, counters, task, partial, qpad, tauq, total;
 };
 static void blayout(long long Q, int P, int k, long long max_tasks, long long nb, int d, bool tiled, BWs *w) {
     size_t o = 0;
@@ -475,6 +499,7 @@ static void blayout(long long Q, int P, int k, long long max_tasks, long long nb
     w->task = o;     o += ws_align((size_t)max_tasks * sizeof(int4));
     w->partial = o;  o += ws_align((size_t)max_tasks * (tiled ? TILED_QB : 8) * k * 8);
     w->qpad = o;     o += tiled ? ws_align((size_t)Q * ((d + 3) / 4) * 16) : 0;
+    w->tauq = o;     o += ws_align((size_t)Q * 8);
     w->total = o;
 }
 
@@ -502,7 +527,7 @@ int bucket_scan_run(const BucketScanCall &c) {
     BArgs a;
     a.corpus = c.corpus; a.row_stride = c.row_stride; a.d = c.d; a.gid = c.gid; a.uniq = c.uniq; a.offsets = c.offsets; a.nb = c.nb;
     a.inv_norm = c.inv_norm; a.queries = c.queries; a.q_stride = c.q_stride; a.Q = c.Q; a.qkeys = c.qkeys; a.nkeys = c.nkeys;
-    a.P = c.P; a.k = c.k; a.seg = c.seg; a.QB = c.tiled ? TILED_QB : (d4 <= 64 ? 8 : (d4 <= 128 ? 4 : 2));
+    a.P = c.P; a.k = c.k; a.seg = c.tiled ? 64 * TILED_TPS : c.seg; a.QB = c.tiled ? TILED_QB : (d4 <= 64 ? 8 : (d4 <= 128 ? 4 : 2));
     a.qpad_w = (float *)((char *)c.workspace + w.qpad); a.qpad = a.qpad_w; a.qpad_stride = (long long)d4 * 4; a.d4p = d4;
     // L2 with d % 4 == 0 needs neither padding nor normalisation: read the caller's queries directly
     const bool prep = c.tiled && !(c.metric == NLSH_METRIC_L2_EPS && (c.d & 3) == 0 && (c.q_stride & 3) == 0 && ((uintptr_t)c.queries & 15) == 0);
@@ -513,8 +538,10 @@ int bucket_scan_run(const BucketScanCall &c) {
     a.bcount = (int32_t *)(base + w.bcount); a.pairoff = (int32_t *)(base + w.pairoff); a.taskoff = (int32_t *)(base + w.taskoff);
     a.counters = (int32_t *)(base + w.counters); a.task = (int4 *)(base + w.task); a.partial = (uint64_t *)(base + w.partial);
     a.max_tasks = c.max_tasks;
+    a.tauq = (unsigned long long *)(base + w.tauq);
 
     hipStream_t s = c.stream;
+    NLSH_CHECK_HIP(hipMemsetAsync(a.tauq, 0xFF, (size_t)c.Q * 8, s));  // KEY_NONE
     NLSH_CHECK_HIP(hipMemsetAsync(c.status, 0, 2 * sizeof(int32_t), s));
     NLSH_CHECK_HIP(hipMemsetAsync(a.counters, 0, 16, s));
     NLSH_CHECK_HIP(hipMemsetAsync(a.bcount, 0, (size_t)(c.nb > 0 ? c.nb : 1) * 4, s));
@@ -529,8 +556,8 @@ int bucket_scan_run(const BucketScanCall &c) {
         if (c.tiled) {
             const unsigned grid = (unsigned)c.max_tasks;  // one workgroup per task
             // QW = 4 queries per wave (SGPR budget: two chunks x QW x 4 scalar values in flight), NW = 4 waves
-            if (c.metric == NLSH_METRIC_L2_EPS) hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_L2_EPS, 4, TILED_QB / 4>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
-            else hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_COSINE, 4, TILED_QB / 4>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
+            if (c.metric == NLSH_METRIC_L2_EPS) hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_L2_EPS, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
+            else hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_COSINE, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
         } else {
             const unsigned grid = (unsigned)((c.max_tasks + 3) / 4);  // one wavefront per task
             if (c.metric == NLSH_METRIC_L2_EPS) launch_bscan2<NLSH_METRIC_L2_EPS>(a, d4, grid, s);

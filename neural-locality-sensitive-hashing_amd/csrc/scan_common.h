@@ -67,9 +67,20 @@ __device__ __forceinline__ void topk_offer(uint64_t &top, uint64_t &tau, uint64_
         const uint64_t c = read_lane64(key, src);
         if (c < tau) {
             topk_insert(top, c, lane);
-            tau = read_lane64(top, k - 1);
+            const uint64_t kth = read_lane64(top, k - 1);
+            tau = kth < tau ? kth : tau;  // never rises: tau may start from a bound published by another list
         }
     }
+}
+
+// Per-query running bound shared by all lists of a query (agent-scope relaxed atomics: sc1 load / atomic umin).
+// tau semantics in topk_offer: a key is inserted iff key < tau, so the published bound is (k-th best key + 1).
+__device__ __forceinline__ uint64_t global_tau_load(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void global_tau_publish(unsigned long long *p, uint64_t top, int k, int lane) {
+    const uint64_t kth = read_lane64(top, k - 1);
+    if (kth != KEY_NONE && lane == 0) atomicMin(p, (unsigned long long)kth + 1ull);
 }
 
 __device__ __forceinline__ void store_topk(float *out_dist, int32_t *out_idx, uint64_t *out_keys, long long q, int k,
