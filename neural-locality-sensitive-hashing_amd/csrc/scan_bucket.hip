@@ -405,36 +405,34 @@ __global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
     // Lists of the same query in other tasks publish their k-th best key to tauq[q] (atomicMin): no
     // candidate above it can reach the final top-k, so it pre-filters this list (fewer insertions).
     // Which partial entries survive depends on timing; the merged result does not.
-    uint64_t top[QW], tau[QW];
-#pragma unroll
-    for (int jq = 0; jq < QW; ++jq) {
-        top[jq] = KEY_NONE;
-        tau[jq] = jq < nqw ? global_tau_load(a.tauq + qid[jq]) : KEY_NONE;
-    }
+    // All <= 64*TPS candidates of a list exist at once here (TPS keys per lane), so the k best are
+    // SELECTED (bisection + compaction, select_k_smallest) instead of inserted one by one.
+    int32_t mygid[TPS];
+    float myinv[TPS];
+    bool valid[TPS];
 #pragma unroll
     for (int tl = 0; tl < TPS; ++tl) {
-        if (tl < ntile) {
-            const bool valid = tl * 64 + lane < nrows;
-            const int prow = row0 + tl * 64 + (valid ? lane : 0);
-            const int32_t mygid = valid ? a.gid[prow] : -1;
-            float myinv = 0.0f;
-            if (METRIC == NLSH_METRIC_COSINE) myinv = valid ? a.inv_norm[prow] : 0.0f;
-#pragma unroll
-            for (int jq = 0; jq < QW; ++jq) {
-                if (jq < nqw) {
-                    const float dist = finish_distance<METRIC>(acc[tl][jq], myinv);
-                    const uint64_t key = valid ? make_key(dist, mygid) : KEY_NONE;
-                    if (NLSH_ABLATE != 3) topk_offer(top[jq], tau[jq], key, a.k, lane);
-                    else top[jq] ^= key;
-                }
-            }
-        }
+        valid[tl] = tl * 64 + lane < nrows;
+        const int prow = row0 + (valid[tl] ? tl * 64 + lane : 0);
+        mygid[tl] = valid[tl] ? a.gid[prow] : -1;
+        myinv[tl] = (METRIC == NLSH_METRIC_COSINE && valid[tl]) ? a.inv_norm[prow] : 0.0f;
     }
 #pragma unroll
     for (int jq = 0; jq < QW; ++jq) {
         if (jq < nqw) {
-            if (lane < a.k) a.partial[((long long)t * (QW * NW) + wave * QW + jq) * a.k + lane] = top[jq];
-            global_tau_publish(a.tauq + qid[jq], top[jq], a.k, lane);
+            const uint64_t tau_g = global_tau_load(a.tauq + qid[jq]);
+            uint64_t key[TPS];
+#pragma unroll
+            for (int tl = 0; tl < TPS; ++tl) {
+                const float dist = finish_distance<METRIC>(acc[tl][jq], myinv[tl]);
+                const uint64_t kk = valid[tl] ? make_key(dist, mygid[tl]) : KEY_NONE;
+                key[tl] = kk < tau_g ? kk : KEY_NONE;  // beyond another list's k-th best: cannot reach the final top-k
+            }
+            uint64_t *out = a.partial + ((long long)t * (QW * NW) + wave * QW + jq) * a.k;
+            if (NLSH_ABLATE != 3) {
+                const uint64_t bound = select_k_smallest<TPS>(key, a.k, lane, out);
+                if (bound != KEY_NONE && lane == 0) atomicMin(a.tauq + qid[jq], (unsigned long long)bound);
+            } else if (lane < a.k) out[lane] = key[0];
         }
     }
 }

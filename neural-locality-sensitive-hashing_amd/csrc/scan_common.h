@@ -83,6 +83,66 @@ __device__ __forceinline__ void global_tau_publish(unsigned long long *p, uint64
     if (kth != KEY_NONE && lane == 0) atomicMin(p, (unsigned long long)kth + 1ull);
 }
 
+// k smallest of the wave's NK*64 keys (NK per lane, KEY_NONE = absent), written UNSORTED to out[0..k)
+// (KEY_NONE padded), without any ordered insertion: a 32-step bisection on the distance word finds
+// the k-th distance with ballots + scalar popcounts (one short dependent chain per step instead of
+// ~350 cycles per inserted key), exact-distance ties are cut by a second bisection on the id word,
+// and the survivors are compacted with mbcnt prefix counts.  Returns the exclusive bound to publish
+// for the query ((d_k + 1) << 32, every key above it is beyond this list's k-th best) or KEY_NONE
+// when the list holds fewer than k keys.
+template <int NK>
+__device__ __forceinline__ uint64_t select_k_smallest(const uint64_t (&key)[NK], int k, int lane, uint64_t *out) {
+    uint32_t hi[NK], lo[NK];
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+        hi[i] = (uint32_t)(key[i] >> 32);
+        lo[i] = (uint32_t)key[i];
+        n += __popcll(__ballot(key[i] != KEY_NONE));
+    }
+    uint32_t dk = 0xFFFFFFFFu, idk = 0xFFFFFFFFu;  // take everything present (hi of a present key < 0xFFFFFFFF)
+    if (n >= k) {
+        uint32_t a = 0, b = 0xFFFFFFFEu;
+        while (a < b) {  // smallest d with #{hi <= d} >= k
+            const uint32_t mid = a + ((b - a) >> 1);
+            int cnt = 0;
+#pragma unroll
+            for (int i = 0; i < NK; ++i) cnt += __popcll(__ballot(hi[i] <= mid));
+            if (cnt >= k) b = mid; else a = mid + 1;
+        }
+        dk = a;
+        int c_less = 0, c_eq = 0;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            c_less += __popcll(__ballot(hi[i] < dk));
+            c_eq += __popcll(__ballot(hi[i] == dk));
+        }
+        const int need = k - c_less;  // >= 1 keys to take among those at distance d_k
+        if (c_eq > need) {            // exact distance ties: smallest ids win
+            a = 0; b = 0xFFFFFFFFu;
+            while (a < b) {
+                const uint32_t mid = a + ((b - a) >> 1);
+                int cnt = 0;
+#pragma unroll
+                for (int i = 0; i < NK; ++i) cnt += __popcll(__ballot(hi[i] == dk && lo[i] <= mid));
+                if (cnt >= need) b = mid; else a = mid + 1;
+            }
+            idk = a;
+        }
+    }
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+        const bool sel = key[i] != KEY_NONE && (hi[i] < dk || (hi[i] == dk && lo[i] <= idk));
+        const unsigned long long m = __ballot(sel);
+        const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (sel) out[pos] = key[i];
+        base += __popcll(m);
+    }
+    if (lane >= base && lane < k) out[lane] = KEY_NONE;
+    return n >= k ? ((uint64_t)dk + 1ull) << 32 : KEY_NONE;
+}
+
 __device__ __forceinline__ void store_topk(float *out_dist, int32_t *out_idx, uint64_t *out_keys, long long q, int k,
                                            uint64_t top, int lane) {
     if (lane < k) {
