@@ -40,10 +40,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=int(os.environ.get("NLSH_BENCH_N", 1_000_000)))
+    ap.add_argument("--workload", default="sift1m", choices=["sift1m", "glove"],
+                    help="sift1m = BASELINE.json configs[1] (headline); glove = configs[2] (1,183,514 x 100-d, cosine, 24-bit)")
+    ap.add_argument("--n", type=int, default=int(os.environ.get("NLSH_BENCH_N", 0)))
     ap.add_argument("--q", type=int, default=int(os.environ.get("NLSH_BENCH_Q", 10_000)))
-    ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--hash-size", type=int, default=16)
+    ap.add_argument("--dim", type=int, default=0)
+    ap.add_argument("--hash-size", type=int, default=0)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--hash-times", type=int, default=10)
     ap.add_argument("--seg-rows", type=int, default=0)
@@ -73,7 +75,7 @@ def main():
             dist.init_process_group(backend)
 
     from nlsh_amd import _capi, synth
-    from nlsh_amd.data import SIFT, brute_force_topk
+    from nlsh_amd.data import Glove, SIFT, brute_force_topk
     from nlsh_amd.distributed import gather_and_merge, shard_range
     from nlsh_amd.encoders import MultiLayerRelu
     from nlsh_amd.hashings import MultivariateBernoulli
@@ -81,20 +83,31 @@ def main():
     from nlsh_amd.metrics import calculate_recall
     _capi.lib()  # fail loudly if the HIP library is missing
 
-    N, Q, d, H, k, P = args.n, args.q, args.dim, args.hash_size, args.k, args.hash_times
+    wl = {"sift1m": dict(N=1_000_000, d=128, H=16, metric="l2", ckpt="sift1m_manifold_h16.npz", cfg="configs[1]: SIFT1M-shaped "
+                         "(synthetic SIFT-like integers on a 6-d latent manifold, synth.sift_manifold, standardised)"),
+          "glove": dict(N=1_183_514, d=100, H=24, metric="cosine", ckpt="glove_manifold_h24.npz", cfg="configs[2]: GloVe-1.2M-shaped "
+                        "(synthetic 100-d embeddings on an 8-d latent manifold, synth.glove_manifold, cosine)")}[args.workload]
+    N, d, H = args.n or wl["N"], args.dim or wl["d"], args.hash_size or wl["H"]
+    args.hash_size_eff = H
+    Q, k, P, metric = args.q, args.k, args.hash_times, wl["metric"]
     t_setup = time.time()
-    corpus_h, mean, std = synth.standardise(synth.sift_manifold(N, d, seed=synth.SEED_DATA))
-    queries_h, _, _ = synth.standardise(synth.sift_manifold(Q, d, seed=synth.SEED_QUERY), mean, std)
-    ckpt = os.path.join(ROOT, "neural-locality-sensitive-hashing_amd", "checkpoints", "sift1m_manifold_h16.npz")
-    if d == 128 and H == 16 and os.path.exists(ckpt) and not args.random_init:
+    if args.workload == "sift1m":
+        corpus_h, mean, std = synth.standardise(synth.sift_manifold(N, d, seed=synth.SEED_DATA))
+        queries_h, _, _ = synth.standardise(synth.sift_manifold(Q, d, seed=synth.SEED_QUERY), mean, std)
+    else:
+        corpus_h = synth.glove_manifold(N, d, seed=synth.SEED_DATA)
+        queries_h = synth.glove_manifold(Q, d, seed=synth.SEED_QUERY)
+    ckpt = os.path.join(ROOT, "neural-locality-sensitive-hashing_amd", "checkpoints", wl["ckpt"])
+    if d == wl["d"] and H == wl["H"] and os.path.exists(ckpt) and not args.random_init:
         arrs = np.load(ckpt)
         Ws, bs = [arrs[f"W{i}"] for i in range(3)], [arrs[f"b{i}"] for i in range(3)]
-        hash_desc = ("learned: triplet loss (margin 1.0, random negatives, 5000 Adam steps, tools/train_hash.py) on this "
-                     "synthetic corpus, 128->256->256->16, checkpoints/sift1m_manifold_h16.npz")
+        hash_desc = (f"learned: triplet loss (margin 1.0, random negatives, 5000 Adam steps, tools/train_hash.py) on this "
+                     f"synthetic corpus, {d}->256->256->{H}, checkpoints/{wl['ckpt']}")
     else:
         Ws, bs = synth.make_weights([d, 256, 256, H], seed=synth.SEED_WEIGHTS)
         hash_desc = f"seeded nn.Linear-default init {d}->256->256->{H} (random-init hash)"
-    hashing = MultivariateBernoulli(MultiLayerRelu(d, [256, 256]), H, None, compat=True)
+    # keys wrap to int16 like the reference (nlsh/utils.pyx:7-15) up to 16 bits; wider hashes use the full code
+    hashing = MultivariateBernoulli(MultiLayerRelu(d, [256, 256]), H, None, compat=H <= 16)
     lin = [m for m in hashing._hasher.modules() if isinstance(m, torch.nn.Linear)]
     with torch.no_grad():
         for m, W, b in zip(lin, Ws, bs):
@@ -107,7 +120,8 @@ def main():
     queries = torch.from_numpy(queries_h).to(dev)
     torch.cuda.synchronize()
     t0 = time.time()
-    indexer = Indexer(hashing, shard, SIFT.distance, id_base=lo, seg_rows=args.seg_rows, algo=args.algo)
+    indexer = Indexer(hashing, shard, SIFT.distance if metric == "l2" else Glove.distance, compat=H <= 16, id_base=lo,
+                      seg_rows=args.seg_rows, algo=args.algo)
     torch.cuda.synchronize()
     build_s = time.time() - t0
     stats = indexer.bucket_stats()
@@ -168,46 +182,47 @@ def main():
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
         w = tr["workload"]
-        if (w["N"], w["d"], w["Q"], w["H"], w["hash_times"]) == (N, d, Q, H, P) and world == 1 and "learned" in hash_desc:
+        if (w["N"], w["d"], w["Q"], w["H"], w["hash_times"]) == (N, d, Q, H, P) and world == 1 and "learned" in hash_desc \
+                and args.workload == "sift1m":
             traffic = tr["traffic_bytes_per_launch"].get(str(indexer.last_algo))
     except (OSError, KeyError, ValueError):
         pass
 
     result = None
     if rank == 0:
-        gt = brute_force_topk(queries, torch.from_numpy(corpus_h).to(dev), k, "l2").cpu().numpy()
+        gt = brute_force_topk(queries, torch.from_numpy(corpus_h).to(dev), k, metric).cpu().numpy()
         idx_h = idx_.cpu().numpy()
         recall = float(np.mean(calculate_recall(list(gt), [r[r >= 0].tolist() for r in idx_h])))
         mean_c = float(nc_.float().mean().item())
         value = Q * steps / elapsed
         result = {
-            "metric": "queries/sec + recall@10, SIFT1M 128-d 16-bit hash, 1/2/4/8 GPU",
+            "metric": "queries/sec + recall@10, SIFT1M 128-d 16-bit hash, 1/2/4/8 GPU" if args.workload == "sift1m" else
+                      "queries/sec + recall@10 (GloVe-1.2M 100-d cosine 24-bit: BASELINE.json configs[2], not the headline)",
             "value": value, "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "recall_at_10": recall,
-            "config": {"workload": "configs[1]: SIFT1M-shaped (synthetic SIFT-like integers on a 6-d latent manifold, "
-                                   f"synth.sift_manifold, standardised), N={N} d={d} Q={Q} H={H} k={k} hash_times={P}",
+            "config": {"workload": f"{wl['cfg']}, N={N} d={d} Q={Q} H={H} k={k} hash_times={P}",
                        "hash": hash_desc,
                        "parallelism": f"corpus rows sharded x{world}, all-gather top-k" if world > 1 else "single GPU",
                        "n_buckets": stats["n_indexes"], "bucket_mean": stats["mean"], "bucket_median": stats["median"],
                        "bucket_max": stats["max"], "mean_candidates_per_query": mean_c,
                        "index_build_s": build_s, "api_list_qps": api_qps},
-            "roofline": {"bound": "hbm", "kernel": {0: "scan_kernel<32,1,L2> (query-major)", 1: "bscan2_kernel<32,1,L2,8> (bucket-major)", 2: "bscan3_kernel<L2> (bucket-major, LDS-tiled)"}[indexer.last_algo], "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": {0: "scan_kernel (query-major)", 1: "bscan2_kernel (bucket-major, 8 queries in registers)", 2: "bscan3_kernel (bucket-major, LDS-tiled)"}[indexer.last_algo] + " " + metric, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "note": "achieved = ALGORITHMIC bytes (4*d*sum C_q) / kernel time; the bucket-major schedules fetch each row once per query GROUP, so frac > 1 means HBM traffic (see traffic, bytes/launch from PMC) is far below the algorithmic bytes and the kernel is fp32-VALU-bound",
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms,
                          "sum_candidates_per_launch": sum_c_local, "tasks_per_launch": n_tasks},
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args, corpus_h, queries_h, Ws, bs, indexer, hashing, queries, steps)
+            result["cpu_baseline"] = cpu_baseline(args, corpus_h, queries_h, Ws, bs, indexer, hashing, queries, steps, metric)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, corpus_h, queries_h, Ws, bs, indexer, hashing, queries, steps):
+def cpu_baseline(args, corpus_h, queries_h, Ws, bs, indexer, hashing, queries, steps, metric):
     """CPU oracle (oracle/: C + OpenMP scan, BLAS forward) on a bounded sample of the same workload:
     same queries, same multi-probe keys (so identical candidate sets), same k."""
     from oracle import oracle
@@ -215,6 +230,8 @@ def cpu_baseline(args, corpus_h, queries_h, Ws, bs, indexer, hashing, queries, s
     keys, nkeys = indexer.hash_device(queries, hash_times=P, seed=1000 + steps - 1)
     kh, nh = keys.cpu().numpy().astype(np.int64), nkeys.cpu().numpy()
     ck = indexer.corpus_keys.cpu().numpy().astype(np.int64)
+    if args.hash_size_eff > 16:  # full-width keys travel as int32 bit patterns
+        ck, kh = ck & 0xFFFFFFFF, kh & 0xFFFFFFFF
     perm, uniq, offs = oracle.build_csr(ck)
     threads = oracle.num_threads()
 
@@ -222,9 +239,9 @@ def cpu_baseline(args, corpus_h, queries_h, Ws, bs, indexer, hashing, queries, s
         t0 = time.perf_counter()
         z = oracle.mlp_forward_blas(queries_h[:sample], Ws, bs)
         _, p01 = oracle.head_probs(z)
-        oracle.row_keys(p01, P, "ref_int16", seed=1000 + steps - 1, n_multi_rows=(sample // 4096) * 4096)
+        oracle.row_keys(p01, P, "ref_int16" if args.hash_size_eff <= 16 else "full", seed=1000 + steps - 1, n_multi_rows=(sample // 4096) * 4096)
         t1 = time.perf_counter()
-        oracle.query_batch(corpus_h, perm, uniq, offs, queries_h[:sample], kh[:sample], nh[:sample], k, "l2")
+        oracle.query_batch(corpus_h, perm, uniq, offs, queries_h[:sample], kh[:sample], nh[:sample], k, metric)
         t2 = time.perf_counter()
         return t1 - t0, t2 - t1
 

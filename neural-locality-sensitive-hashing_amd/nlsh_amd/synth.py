@@ -59,6 +59,30 @@ def sift_manifold(n, d=128, seed=SEED_DATA, latent_dim=6, n_clusters=32, spread=
     return out
 
 
+def glove_manifold(n, d=100, seed=SEED_DATA, latent_dim=8, n_clusters=64, spread=0.6, chunk=1 << 16):
+    """Real-valued embedding-like rows with low intrinsic dimension (cosine workloads): a random smooth
+    map of a `latent_dim`-d Gaussian mixture, centred, plus 5 % isotropic noise.  Same motivation as
+    `sift_manifold`: `glove_like` is isotropic, so its cosine k-NN are arbitrary."""
+    g = np.random.default_rng(SEED_CENTRES + 11)
+    A1 = g.standard_normal((latent_dim, 96)).astype(np.float32)
+    b1 = g.uniform(-1, 1, size=96).astype(np.float32)
+    A2 = (g.standard_normal((96, d)) / 9.8).astype(np.float32)
+    cen = g.standard_normal((n_clusters, latent_dim)).astype(np.float32)
+
+    def fmap(z):
+        return np.tanh(z @ A1 + b1) @ A2
+
+    cal = fmap(cen[g.integers(0, n_clusters, 8192)] + spread * g.standard_normal((8192, latent_dim)).astype(np.float32))
+    mu = cal.mean(axis=0).astype(np.float32)
+    rng = np.random.default_rng(seed)
+    out = np.empty((n, d), dtype=np.float32)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        z = cen[rng.integers(0, n_clusters, size=e - s)] + np.float32(spread) * rng.standard_normal((e - s, latent_dim), dtype=np.float32)
+        out[s:e] = fmap(z) - mu + np.float32(0.05) * rng.standard_normal((e - s, d), dtype=np.float32)
+    return out
+
+
 def glove_like(n, d=100, seed=SEED_DATA, chunk=1 << 16):
     """N(0,1) rows with a fixed per-dimension scale in U(0.3, 1.0) (cosine workloads)."""
     scale = np.random.default_rng(SEED_CENTRES + 1).uniform(0.3, 1.0, size=d).astype(np.float32)

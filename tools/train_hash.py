@@ -53,8 +53,8 @@ def main():
         queries, _, _ = synth.standardise(gen(args.q, d, seed=synth.SEED_QUERY), mean, std)
     else:
         d, metric, dist_fn = 100, "cosine", Glove.distance
-        corpus = synth.glove_like(args.n, d, seed=synth.SEED_DATA)
-        queries = synth.glove_like(args.q, d, seed=synth.SEED_QUERY)
+        corpus = synth.glove_manifold(args.n, d, seed=synth.SEED_DATA)
+        queries = synth.glove_manifold(args.q, d, seed=synth.SEED_QUERY)
     cg, qg = torch.from_numpy(corpus).cuda(), torch.from_numpy(queries).cuda()
     t0 = time.time()
     knn = training.self_knn(cg, max(args.positive_k, args.knn_k, args.neg_band[1] if args.neg_band else 0), metric=metric)
