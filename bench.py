@@ -121,7 +121,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.time()
     indexer = Indexer(hashing, shard, SIFT.distance if metric == "l2" else Glove.distance, compat=H <= 16, id_base=lo,
-                      seg_rows=args.seg_rows, algo=args.algo)
+                      seg_rows=args.seg_rows, algo=args.algo, stats_scale=world)
     torch.cuda.synchronize()
     build_s = time.time() - t0
     stats = indexer.bucket_stats()

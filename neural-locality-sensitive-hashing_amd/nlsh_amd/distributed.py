@@ -65,6 +65,7 @@ class ShardedIndexer:
     def __init__(self, hashing, local_corpus_gpu, distance_func, id_base: int, group=None, **kw):
         from .indexer import Indexer
         self.group = group
+        kw.setdefault("stats_scale", dist.get_world_size(group) if dist.is_initialized() else 1)
         self.local = Indexer(hashing, local_corpus_gpu, distance_func, id_base=id_base, **kw)
 
     def query_tensors(self, query_vectors, k=10, hash_times=10, seed=0, check=True, events=None):

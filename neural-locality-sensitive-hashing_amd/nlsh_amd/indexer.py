@@ -85,14 +85,17 @@ def build_index(indexes, cuda=True) -> Dict[int, torch.Tensor]:
 class Indexer:
 
     def __init__(self, hashing, candidate_vectors_gpu, distance_func, compat=True, metric: Optional[str] = None,
-                 seg_rows: int = 0, id_base: int = 0, algo: Optional[str] = None):
+                 seg_rows: int = 0, id_base: int = 0, algo: Optional[str] = None, stats_scale: float = 1.0):
         self._hashing = hashing
         self._candidate_vectors_gpu = candidate_vectors_gpu
         self._distance_func = distance_func
         self.compat = compat
         self.metric = metric or metric_of(distance_func)
         self.seg_rows = seg_rows
-        self.algo = algo            # None = choose per batch; "query" | "bucket" force a schedule
+        self.algo = algo            # None = choose per batch; "query" | "bucket" | "tiled" force a schedule
+        # number of equal shards the full corpus was split into: the schedule is chosen from the statistics of
+        # the WHOLE corpus, so every shard count runs the same arithmetic and results stay bit-identical
+        self.stats_scale = float(stats_scale)
         self.id_base = int(id_base)
         self._index2row = None
         self._ws = None
@@ -172,8 +175,8 @@ class Indexer:
         if self.algo is not None:
             return {"query": _capi.SCAN_QUERY_MAJOR, "bucket": _capi.SCAN_BUCKET_MAJOR, "tiled": _capi.SCAN_BUCKET_TILED}[self.algo]
         n = max(float(self.bucket_sizes.sum()), 1.0)
-        e_sb = self._size_biased_bucket()
-        reuse = Q * P * e_sb / n
+        e_sb = self._size_biased_bucket() * self.stats_scale
+        reuse = Q * P * e_sb / (n * self.stats_scale)
         if e_sb >= 256 and reuse >= 8.0:
             return _capi.SCAN_BUCKET_TILED
         if e_sb >= 128 and reuse >= 3.0:

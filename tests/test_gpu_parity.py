@@ -334,7 +334,7 @@ def test_sharded_scan_plus_merge_equals_single_index(G):
     keys_all, nc_all = [], []
     for r in range(G):
         lo, hi = shard_range(N, r, G)
-        sh = Indexer(hashing, dev(corpus[lo:hi]), SIFT.distance, id_base=lo)
+        sh = Indexer(hashing, dev(corpus[lo:hi]), SIFT.distance, id_base=lo, stats_scale=G)   # as ShardedIndexer does
         _, _, nc, k64 = sh.query_tensors(qd, k=k, hash_times=P, seed=77, want_keys=True)
         keys_all.append(k64); nc_all.append(nc)
     dm, im, nm = merge_topk_device(torch.stack(keys_all), torch.stack(nc_all), k)
