@@ -146,10 +146,12 @@ int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, int d, const 
                    int32_t *status, void *workspace, size_t workspace_bytes, int64_t max_tasks,
                    void *ev_scan_begin, void *ev_scan_end, nlsh_stream_t stream);
 
-/* Merge G per-shard top-k lists per query (keys_in [dev] [G, Q, k], as all-gathered from
- * nlsh_scan_topk's out_keys) into the global top-k; same comparator, so the result equals the
- * single-GPU result.  ncand_in (nullable) [G, Q] is summed into out_ncand. */
-int nlsh_merge_topk(const uint64_t *keys_in, int G, int64_t Q, int k, const int32_t *ncand_in,
+/* Merge G per-shard top-k lists per query (keys_in [dev] [G, Q, row_stride] u64, the first k of each
+ * row as all-gathered from nlsh_scan_topk's out_keys) into the global top-k; same comparator, so the
+ * result equals the single-GPU result.  Candidate counts are summed into out_ncand from ncand_in
+ * (nullable) [G, Q], or, when ncand_in is NULL and row_stride > k, from element k of every row (so one
+ * collective can carry keys and counts together). */
+int nlsh_merge_topk(const uint64_t *keys_in, int64_t row_stride, int G, int64_t Q, int k, const int32_t *ncand_in,
                     float *out_dist, int32_t *out_idx, int32_t *out_ncand, nlsh_stream_t stream);
 
 #ifdef __cplusplus

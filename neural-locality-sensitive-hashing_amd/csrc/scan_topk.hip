@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void merge_segments_kernel(ScanArgs a) {
     store_topk(a.out_dist, a.out_idx, a.out_keys, q, a.k, top, lane);
 }
 
-__global__ __launch_bounds__(256) void merge_shards_kernel(const uint64_t *keys_in, int G, long long Q, int k,
+__global__ __launch_bounds__(256) void merge_shards_kernel(const uint64_t *keys_in, long long row_stride, int G, long long Q, int k,
                                                             const int32_t *ncand_in, float *out_dist, int32_t *out_idx,
                                                             int32_t *out_ncand) {
     const int lane = threadIdx.x & 63;
@@ -224,12 +224,14 @@ __global__ __launch_bounds__(256) void merge_shards_kernel(const uint64_t *keys_
     uint64_t top = KEY_NONE, tau = KEY_NONE;
     int32_t nc = 0;
     for (int g = 0; g < G; ++g) {
-        const uint64_t key = lane < k ? keys_in[((long long)g * Q + q) * k + lane] : KEY_NONE;
+        const uint64_t *row = keys_in + ((long long)g * Q + q) * row_stride;
+        const uint64_t key = lane < k ? row[lane] : KEY_NONE;
         topk_offer(top, tau, key, k, lane);
         if (ncand_in) nc += ncand_in[(long long)g * Q + q];
+        else if (row_stride > k) nc += (int32_t)row[k];
     }
     store_topk(out_dist, out_idx, nullptr, q, k, top, lane);
-    if (out_ncand && ncand_in && lane == 0) out_ncand[q] = nc;
+    if (out_ncand && (ncand_in || row_stride > k) && lane == 0) out_ncand[q] = nc;
 }
 
 struct ScanWs {
@@ -328,13 +330,14 @@ extern "C" int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, in
     return NLSH_OK;
 }
 
-extern "C" int nlsh_merge_topk(const uint64_t *keys_in, int G, int64_t Q, int k, const int32_t *ncand_in, float *out_dist,
-                               int32_t *out_idx, int32_t *out_ncand, nlsh_stream_t stream) {
-    NLSH_REQUIRE(G >= 1 && Q >= 0 && k >= 1 && k <= NLSH_MAX_K, NLSH_E_INVALID, "merge_topk: G=%d Q=%lld k=%d", G, (long long)Q, k);
+extern "C" int nlsh_merge_topk(const uint64_t *keys_in, int64_t row_stride, int G, int64_t Q, int k, const int32_t *ncand_in,
+                               float *out_dist, int32_t *out_idx, int32_t *out_ncand, nlsh_stream_t stream) {
+    NLSH_REQUIRE(G >= 1 && Q >= 0 && k >= 1 && k <= NLSH_MAX_K && row_stride >= k, NLSH_E_INVALID,
+                 "merge_topk: G=%d Q=%lld k=%d row_stride=%lld", G, (long long)Q, k, (long long)row_stride);
     if (Q == 0) return NLSH_OK;
     NLSH_REQUIRE(keys_in && out_dist && out_idx, NLSH_E_INVALID, "merge_topk: null pointer");
-    hipLaunchKernelGGL(merge_shards_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, (hipStream_t)stream, keys_in, G, (long long)Q, k,
-                       ncand_in, out_dist, out_idx, out_ncand);
+    hipLaunchKernelGGL(merge_shards_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, (hipStream_t)stream, keys_in, (long long)row_stride, G,
+                       (long long)Q, k, ncand_in, out_dist, out_idx, out_ncand);
     NLSH_CHECK_HIP(hipGetLastError());
     return NLSH_OK;
 }

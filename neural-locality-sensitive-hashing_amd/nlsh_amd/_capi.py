@@ -76,7 +76,7 @@ def lib():
     L.nlsh_scan_topk.argtypes = [vp, i64, i32, vp, vp, vp, ctypes.c_int32, vp, vp, i64, i64, vp, vp, i32, i32, i32, i32, i32,
                                  vp, vp, vp, vp, vp, vp, sz, i64, vp, vp, vp]
     L.nlsh_merge_topk.restype = i32
-    L.nlsh_merge_topk.argtypes = [vp, i32, i64, i32, vp, vp, vp, vp, vp]
+    L.nlsh_merge_topk.argtypes = [vp, i64, i32, i64, i32, vp, vp, vp, vp, vp]
     _lib = L
     return L
 

@@ -10,7 +10,7 @@ exchange step is ONE all-gather (RCCL over xGMI when the backend is "nccl") of t
 Multi-probe keys are identical on every rank because the Philox stream is keyed by
 (seed, global query row, probe) and the hard bits are deterministic.
 """
-from typing import Callable, Optional, Tuple
+from typing import Callable, Tuple
 
 import torch
 import torch.distributed as dist
@@ -25,18 +25,18 @@ def shard_range(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def merge_topk_device(keys_all: torch.Tensor, ncand_all: Optional[torch.Tensor], k: int):
-    """keys_all int64 [G, Q, k] (bit pattern of the uint64 sort keys) -> (dist, idx, ncand) via nlsh_merge_topk."""
-    if keys_all.device.type != "cuda":
+def merge_topk_device(packed_all: torch.Tensor, k: int):
+    """packed_all int64 [G, Q, k+1]: per shard and query the k uint64 sort keys (bit patterns) followed by
+    the shard's candidate count -> (dist, idx, ncand) via nlsh_merge_topk."""
+    if packed_all.device.type != "cuda":
         raise _capi.NlshHipError(_capi.E_INVALID, "merge_topk needs device tensors; there is no CPU path")
-    G, Q, kk = keys_all.shape
-    assert kk == k
-    dev = keys_all.device
+    G, Q, stride = packed_all.shape
+    assert stride == k + 1
+    dev = packed_all.device
     out_dist = torch.empty((Q, k), dtype=torch.float32, device=dev)
     out_idx = torch.empty((Q, k), dtype=torch.int32, device=dev)
-    out_nc = torch.empty((Q,), dtype=torch.int32, device=dev) if ncand_all is not None else None
-    _capi.check(_capi.lib().nlsh_merge_topk(_capi.ptr(keys_all.contiguous()), G, Q, k,
-                                            _capi.ptr(None if ncand_all is None else ncand_all.contiguous()),
+    out_nc = torch.empty((Q,), dtype=torch.int32, device=dev)
+    _capi.check(_capi.lib().nlsh_merge_topk(_capi.ptr(packed_all.contiguous()), stride, G, Q, k, None,
                                             _capi.ptr(out_dist), _capi.ptr(out_idx), _capi.ptr(out_nc),
                                             torch.cuda.current_stream(dev).cuda_stream))
     return out_dist, out_idx, out_nc
@@ -44,19 +44,17 @@ def merge_topk_device(keys_all: torch.Tensor, ncand_all: Optional[torch.Tensor],
 
 def gather_and_merge(local_keys: torch.Tensor, local_ncand: torch.Tensor, k: int, group=None,
                      merge_fn: Callable = merge_topk_device):
-    """The exchange step: all-gather per-rank top-k keys [Q,k] + counts [Q], then merge.
-
-    `merge_fn` is the device merge in production; tests inject a checker to exercise the
+    """The exchange step: ONE all-gather of per-rank rows [Q, k+1] (k top-k keys + candidate count),
+    then merge.  `merge_fn` is the device merge in production; tests inject a checker to exercise the
     collective + layout on the gloo backend without a GPU.
     """
     world = dist.get_world_size(group)
     Q = local_keys.shape[0]
+    packed = torch.cat([local_keys, local_ncand.to(local_keys.dtype)[:, None]], dim=1).contiguous()
     # concatenation form ([world*Q, ...]): accepted by both the nccl (RCCL) and the gloo backend
-    keys_all = torch.empty((world * Q, k), dtype=local_keys.dtype, device=local_keys.device)
-    nc_all = torch.empty((world * Q,), dtype=local_ncand.dtype, device=local_ncand.device)
-    dist.all_gather_into_tensor(keys_all, local_keys.contiguous(), group=group)
-    dist.all_gather_into_tensor(nc_all, local_ncand.contiguous(), group=group)
-    return merge_fn(keys_all.view(world, Q, k), nc_all.view(world, Q), k)
+    packed_all = torch.empty((world * Q, k + 1), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(packed_all, packed, group=group)
+    return merge_fn(packed_all.view(world, Q, k + 1), k)
 
 
 class ShardedIndexer:

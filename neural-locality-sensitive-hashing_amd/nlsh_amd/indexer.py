@@ -185,8 +185,8 @@ class Indexer:
 
     def _estimate_tasks(self, Q, P, seg, algo):
         biased = self._size_biased_bucket()
-        if algo == _capi.SCAN_BUCKET_TILED:
-            est = Q * min(P, 4) * (1.0 / 16 + biased / seg / 16) + self.n_buckets
+        if algo == _capi.SCAN_BUCKET_TILED:   # tasks = (256-row segment, <= 16 queries)
+            est = Q * min(P, 4) * (1.0 / 16 + biased / 256 / 16) + self.n_buckets
         elif algo == _capi.SCAN_BUCKET_MAJOR:
             est = Q * min(P, 4) * (1.0 / 4 + biased / seg / 4) + self.n_buckets
         else:

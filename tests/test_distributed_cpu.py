@@ -26,8 +26,9 @@ def make_keys(dist32, idx32):
     return key.view(np.int64)
 
 
-def merge_numpy(keys_all, nc_all, k):
-    G, Q, _ = keys_all.shape
+def merge_numpy(packed_all, k):
+    G, Q, _ = packed_all.shape
+    keys_all, nc_all = packed_all[:, :, :k].contiguous(), packed_all[:, :, k]
     flat = keys_all.numpy().view(np.uint64).transpose(1, 0, 2).reshape(Q, G * k)
     best = np.sort(flat, axis=1)[:, :k]
     idx = np.where(best == np.uint64(0xFFFFFFFFFFFFFFFF), -1, (best & np.uint64(0xFFFFFFFF)).astype(np.int64)).astype(np.int32)

@@ -337,7 +337,8 @@ def test_sharded_scan_plus_merge_equals_single_index(G):
         sh = Indexer(hashing, dev(corpus[lo:hi]), SIFT.distance, id_base=lo, stats_scale=G)   # as ShardedIndexer does
         _, _, nc, k64 = sh.query_tensors(qd, k=k, hash_times=P, seed=77, want_keys=True)
         keys_all.append(k64); nc_all.append(nc)
-    dm, im, nm = merge_topk_device(torch.stack(keys_all), torch.stack(nc_all), k)
+    packed = torch.cat([torch.stack(keys_all), torch.stack(nc_all).long()[:, :, None]], dim=2)
+    dm, im, nm = merge_topk_device(packed, k)
     assert torch.equal(nm, n1)                                      # candidate counts add up exactly
     assert torch.equal(im, i1)                                      # same comparator -> identical ids
     assert torch.equal(dm, d1)                                      # and bit-identical distances
