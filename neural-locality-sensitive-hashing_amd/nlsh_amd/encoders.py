@@ -24,21 +24,12 @@ def _fold_batchnorm(weight, bias, bn: nn.BatchNorm1d) -> LinearSpec:
     return w, (b0 - bn.running_mean) * scale + shift
 
 
-class _ReluMlp(nn.Module):
-    """Linear(+BatchNorm1d)+ReLU stack; subclasses only decide the child-module names."""
-
-    output_dim: int
+class _ReluMlp:
+    """Mixin of the Linear(+BatchNorm1d)+ReLU encoders: exposes the folded Linear stack to the HIP
+    kernel.  `forward` stays TorchScript-compatible in the subclasses (`hashing.save` scripts them)."""
 
     def _blocks(self):
         raise NotImplementedError
-
-    def forward(self, x):
-        for linear, bn in self._blocks():
-            x = linear(x)
-            if bn is not None:
-                x = bn(x)
-            x = torch.relu(x)
-        return x
 
     def linear_stack(self) -> List[LinearSpec]:
         """[(W [out,in], b [out] | None)] with eval-mode BatchNorm folded in: what the HIP kernel packs."""
@@ -51,23 +42,27 @@ class _ReluMlp(nn.Module):
         return out
 
 
-class TwoLayer256Relu(_ReluMlp):
+class TwoLayer256Relu(_ReluMlp, nn.Module):
 
     def __init__(self, input_dim: int, with_bias=True):
-        super().__init__()
+        nn.Module.__init__(self)
         self._input_dim = input_dim
         self.output_dim = 256
         self.fc1 = nn.Linear(input_dim, 256, bias=with_bias)
         self.fc2 = nn.Linear(256, 256, bias=with_bias)
 
+    def forward(self, x):
+        return torch.relu(self.fc2(torch.relu(self.fc1(x))))
+
     def _blocks(self):
         return [(self.fc1, None), (self.fc2, None)]
 
 
-class MultiLayerRelu(_ReluMlp):
+class MultiLayerRelu(_ReluMlp, nn.Sequential):
+    """nn.Sequential of `{i}_linear` [, `{i}_batch_norm`], `{i}_relu` (Sequential's own forward scripts)."""
 
     def __init__(self, input_dim, hidden_dims: List[int], with_batchnorm=False, with_bias=True):
-        super().__init__()
+        nn.Sequential.__init__(self)
         self._input_dim = input_dim
         self._hidden_dims = list(hidden_dims)
         self._with_batchnorm = with_batchnorm

@@ -380,3 +380,27 @@ def test_tiled_schedule_l2_distances_bit_exact_vs_oracle():
         assert np.array_equal(nc.cpu().numpy(), onc)
         assert np.array_equal(idx.cpu().numpy(), oi)
         assert np.array_equal(dist.cpu().numpy().view(np.uint32), od.view(np.uint32))
+
+
+def test_save_then_load_checkpoint_roundtrip(tmp_path):
+    """hashing.save() (TorchScript _cpu/_gpu + state dict, reference hashings.py:53-57) -> io loaders ->
+    a fresh hashing produces bit-identical keys."""
+    from nlsh_amd import io as nio
+    from nlsh_amd.encoders import TwoLayer256Relu
+    from nlsh_amd.hashings import MultivariateBernoulli
+    Ws, bs = synth.make_weights([128, 256, 256, 16], seed=21)
+    hashing = make_hashing(128, None, 16, Ws, bs, two_layer=True)
+    base = str(tmp_path / "run_1_0.5000")
+    hashing.save(base)
+    x, _, _ = synth.standardise(synth.sift_like(500, 128, seed=22))
+    k0, n0 = hashing.hash_device(dev(x), n=4, seed=9)
+    for suffix in ("_cpu.pt", "_gpu.pt", "_state.pt"):
+        W2, b2 = nio.load_hasher_weights(base + suffix)
+        h2 = nio.hashing_from_weights(W2, b2, compat=True)
+        k1, n1 = h2.hash_device(dev(x), n=4, seed=9)
+        assert torch.equal(k0, k1) and torch.equal(n0, n1)
+    h3 = MultivariateBernoulli(TwoLayer256Relu(128), 16, None)
+    h3.load_state(base + "_state.pt")
+    h3.train_mode(False)
+    k2, _ = h3.hash_device(dev(x), n=4, seed=9)
+    assert torch.equal(k0, k2)
