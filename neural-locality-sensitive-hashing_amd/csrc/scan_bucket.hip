@@ -45,7 +45,7 @@ struct BArgs {
     uint64_t *out_keys;
     int32_t *out_ncand;
     int32_t *status;
-    int32_t *pbkt, *pairpos, *inv_q, *bcount, *pairoff, *taskoff, *counters;
+    int32_t *pbkt, *pairpos, *inv_q, *bcount, *pairoff, *taskoff, *bgroups, *counters;
     int4 *task;
     uint64_t *partial;
     long long max_tasks;
@@ -103,12 +103,14 @@ __global__ __launch_bounds__(256) void bscan_kernel(BArgs a) {
     __shared__ int wsum[4];
     __shared__ int base_m, base_t;
     const int b = blockIdx.x * 256 + threadIdx.x;
-    int m = 0, s = 0, ns = 0, nt = 0;
+    int m = 0, s = 0, ns = 0, ng = 0, nt = 0;
     if (b < a.nb) {
         m = a.bcount[b];
         s = a.offsets[b + 1] - a.offsets[b];
         ns = (s + a.seg - 1) / a.seg;
-        nt = ((m + a.QB - 1) / a.QB) * ns;
+        ng = (m + a.QB - 1) / a.QB;
+        nt = ng * ns;
+        a.bgroups[b] = ng;
     }
     int tot_m, tot_t;
     const int ex_m = block_excl_scan(m, wsum, &tot_m);
@@ -126,7 +128,9 @@ __global__ __launch_bounds__(256) void bscan_kernel(BArgs a) {
         for (int t = 0; t < nt; ++t) {
             const long long tt = (long long)to + t;
             if (tt >= a.max_tasks) break;
-            const int gi = t / ns, si = t - gi * ns;
+            // segment-major: the query groups of one row segment get consecutive task ids, so they run
+            // at about the same time (and, with the XCD-chunked block map of bscan3, on one XCD's L2)
+            const int si = t / ng, gi = t - si * ng;
             a.task[tt] = make_int4(po + gi * a.QB, min(a.QB, m - gi * a.QB), row0 + si * a.seg, min(a.seg, s - si * a.seg));
         }
     }
@@ -326,26 +330,32 @@ __global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
     constexpr int RPP = NT / KB;             // rows covered by one pass of the workgroup
     __shared__ float4 tile[ROWS * RS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long t = blockIdx.x;
     long long ntasks = a.status[0];
     if (ntasks > a.max_tasks) {
         if (blockIdx.x == 0 && threadIdx.x == 0) a.status[1] = 1;  // incomplete: caller must retry
         ntasks = a.max_tasks;
     }
-    if (t >= ntasks) return;
+    // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2): give each XCD a
+    // CONTIGUOUS range of task ids, so the query groups of one row segment (consecutive ids) re-read
+    // its rows from that XCD's L2 instead of HBM.  Placement only changes speed, never results.
+    const long long per_xcd = (ntasks + 7) >> 3;
+    const long long t = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((long long)(blockIdx.x >> 3) >= per_xcd || t >= ntasks) return;
     const int4 desc = a.task[t];
     const int pair0 = __builtin_amdgcn_readfirstlane(desc.x);
     const int nq = __builtin_amdgcn_readfirstlane(desc.y);
     const int row0 = __builtin_amdgcn_readfirstlane(desc.z);
     const int nrows = __builtin_amdgcn_readfirstlane(desc.w);  // <= ROWS (the host fixes seg = ROWS)
-    int nqw = nq - wave * QW;
+    // queries are dealt round-robin over the waves (slot = wave + NW*jq): a group of 5 queries costs the
+    // workgroup 2 query-times per stage (2,1,1,1) instead of 4 (4,1,0,0); the stage barrier waits for the slowest wave
+    int nqw = (nq - wave + NW - 1) / NW;
     nqw = __builtin_amdgcn_readfirstlane(nqw < 0 ? 0 : (nqw > QW ? QW : nqw));
 
     const_f32p qs[QW];
     int qid[QW];
 #pragma unroll
     for (int jq = 0; jq < QW; ++jq) {
-        qid[jq] = __builtin_amdgcn_readfirstlane(a.inv_q[pair0 + (jq < nqw ? wave * QW + jq : 0)]);
+        qid[jq] = __builtin_amdgcn_readfirstlane(a.inv_q[pair0 + (jq < nqw ? wave + NW * jq : 0)]);
         qs[jq] = (const_f32p)(a.qpad + (long long)qid[jq] * a.qpad_stride);
     }
 
@@ -428,7 +438,7 @@ __global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
                 const uint64_t kk = valid[tl] ? make_key(dist, mygid[tl]) : KEY_NONE;
                 key[tl] = kk < tau_g ? kk : KEY_NONE;  // beyond another list's k-th best: cannot reach the final top-k
             }
-            uint64_t *out = a.partial + ((long long)t * (QW * NW) + wave * QW + jq) * a.k;
+            uint64_t *out = a.partial + ((long long)t * (QW * NW) + wave + NW * jq) * a.k;
             if (NLSH_ABLATE != 3) {
                 const uint64_t bound = select_k_smallest<TPS>(key, a.k, lane, out);
                 if (bound != KEY_NONE && lane == 0) atomicMin(a.tauq + qid[jq], (unsigned long long)bound);
@@ -446,7 +456,7 @@ __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
     uint64_t top = KEY_NONE, tau = KEY_NONE;
     // lane p resolves probe p (all the dependent index loads of the nk probes overlap), then the
     // wave walks the partial lists with the per-probe values broadcast by v_readlane
-    int ns_l = 0, j_l = 0;
+    int ns_l = 0, j_l = 0, ng_l = 0;
     long long t0_l = 0;
     if (lane < nk) {
         const int b = a.pbkt[q * a.P + lane];
@@ -455,15 +465,17 @@ __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
             const int gi = rel / a.QB;
             j_l = rel - gi * a.QB;
             ns_l = (a.offsets[b + 1] - a.offsets[b] + a.seg - 1) / a.seg;
-            t0_l = (long long)a.taskoff[b] + (long long)gi * ns_l;
+            ng_l = a.bgroups[b];
+            t0_l = (long long)a.taskoff[b] + gi;  // task of (segment si, group gi) = taskoff + si * ngroups + gi
         }
     }
     for (int p = 0; p < nk; ++p) {
         const int ns = __builtin_amdgcn_readlane(ns_l, p);
         const int j = __builtin_amdgcn_readlane(j_l, p);
+        const int ng = __builtin_amdgcn_readlane(ng_l, p);
         const long long t0 = (long long)read_lane64((uint64_t)t0_l, p);
         for (int si = 0; si < ns; ++si) {
-            const long long t = t0 + si;
+            const long long t = t0 + (long long)si * ng;
             if (t >= a.max_tasks) break;  // overflow: status[1] set by the scan kernel
             const uint64_t key = lane < a.k ? a.partial[(t * a.QB + j) * a.k + lane] : KEY_NONE;
             topk_offer(top, tau, key, a.k, lane);
@@ -482,7 +494,7 @@ constexpr int TILED_QB = NLSH_TILED_QB;  // queries per task of the tiled schedu
 constexpr int TILED_TPS = NLSH_TILED_TPS;  // 64-row tiles per task of the tiled schedule (segment = 64*TPS rows)
 
 struct BWs {
-    size_t pbkt, pairpos, inv_q, bcount, pairoff, taskoff, counters, task, partial, qpad, tauq, total;
+    size_t pbkt, pairpos, inv_q, bcount, pairoff, taskoff, bgroups, counters, task, partial, qpad, tauq, total;
 };
 static void blayout(long long Q, int P, int k, long long max_tasks, long long nb, int d, bool tiled, BWs *w) {
     size_t o = 0;
@@ -493,6 +505,7 @@ static void blayout(long long Q, int P, int k, long long max_tasks, long long nb
     w->bcount = o;   o += ws_align(nb4);
     w->pairoff = o;  o += ws_align(nb4);
     w->taskoff = o;  o += ws_align(nb4);
+    w->bgroups = o;  o += ws_align(nb4);
     w->counters = o; o += ws_align(16);
     w->task = o;     o += ws_align((size_t)max_tasks * sizeof(int4));
     w->partial = o;  o += ws_align((size_t)max_tasks * (tiled ? TILED_QB : 8) * k * 8);
@@ -533,7 +546,7 @@ int bucket_scan_run(const BucketScanCall &c) {
     a.out_dist = c.out_dist; a.out_idx = c.out_idx; a.out_keys = c.out_keys; a.out_ncand = c.out_ncand; a.status = c.status;
     char *base = (char *)c.workspace;
     a.pbkt = (int32_t *)(base + w.pbkt); a.pairpos = (int32_t *)(base + w.pairpos); a.inv_q = (int32_t *)(base + w.inv_q);
-    a.bcount = (int32_t *)(base + w.bcount); a.pairoff = (int32_t *)(base + w.pairoff); a.taskoff = (int32_t *)(base + w.taskoff);
+    a.bcount = (int32_t *)(base + w.bcount); a.pairoff = (int32_t *)(base + w.pairoff); a.taskoff = (int32_t *)(base + w.taskoff); a.bgroups = (int32_t *)(base + w.bgroups);
     a.counters = (int32_t *)(base + w.counters); a.task = (int4 *)(base + w.task); a.partial = (uint64_t *)(base + w.partial);
     a.max_tasks = c.max_tasks;
     a.tauq = (unsigned long long *)(base + w.tauq);
@@ -552,7 +565,7 @@ int bucket_scan_run(const BucketScanCall &c) {
     if (c.max_tasks > 0) {
         if (c.ev_begin) NLSH_CHECK_HIP(hipEventRecord((hipEvent_t)c.ev_begin, s));
         if (c.tiled) {
-            const unsigned grid = (unsigned)c.max_tasks;  // one workgroup per task
+            const unsigned grid = (unsigned)(c.max_tasks + 8);  // one workgroup per task (+8: XCD-chunked id map rounds up)
             // QW = 4 queries per wave (SGPR budget: two chunks x QW x 4 scalar values in flight), NW = 4 waves
             if (c.metric == NLSH_METRIC_L2_EPS) hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_L2_EPS, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
             else hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_COSINE, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
