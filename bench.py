@@ -171,6 +171,7 @@ def main():
     # the API-level call (reference return type: Python lists; includes D2H + F7 handling)
     api_qps = None
     if world == 1:
+        indexer.query(queries, k=k, hash_times=P)      # warm-up (first use of the host-side torch ops)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ids_api, nc_api = indexer.query(queries, k=k, hash_times=P)

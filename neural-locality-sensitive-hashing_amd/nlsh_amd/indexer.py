@@ -98,6 +98,7 @@ class Indexer:
         self.stats_scale = float(stats_scale)
         self.id_base = int(id_base)
         self._index2row = None
+        self._perm_host = None
         self._ws = None
         self._max_tasks = {}
         self._build_index()
@@ -256,32 +257,34 @@ class Indexer:
         if i >= len(self._uniq_host) or int(self._uniq_host[i]) != key:
             return []
         lo, hi = int(self._offs_host[i]), int(self._offs_host[i + 1])
-        return (self.perm[lo:hi].long() + self.id_base).cpu().tolist()
+        if self._perm_host is None:   # one D2H of the permutation, then every fallback list is a host slice
+            self._perm_host = self.perm.cpu().numpy().astype(np.int64) + self.id_base
+        return self._perm_host[lo:hi].tolist()
 
     def _to_lists(self, key_sets: Sequence[Sequence[int]], idx, ncand, k):
         idx_h = idx.cpu().numpy()
         nc_h = ncand.cpu().numpy()
-        results = []
-        for qi in range(len(nc_h)):
-            if nc_h[qi] >= k:
-                results.append(idx_h[qi].tolist())
-            elif self.compat:
+        results = idx_h.tolist()                      # one C-level conversion for the whole batch
+        for qi in np.nonzero(nc_h < k)[0].tolist():   # only the short queries need the reference's special case
+            if self.compat:
                 # indexer.py:89-93 (F7): topk raises -> rows of the LAST key of the set iteration
                 order = list(key_sets[qi])
-                results.append(self._rows_of_key(order[-1]) if order else [])
+                results[qi] = self._rows_of_key(order[-1]) if order else []
             else:
-                results.append([int(v) for v in idx_h[qi] if v >= 0])
-        return results, [int(c) for c in nc_h]
+                results[qi] = [int(v) for v in idx_h[qi] if v >= 0]
+        return results, nc_h.tolist()
 
     def query(self, query_vectors, k=10, hash_times=10) -> Tuple[List[List[int]], List[int]]:
         if self.metric not in ("l2", "cosine"):
             return self._query_generic(query_vectors, k, hash_times)
         keys, nkeys = self.hash_device(query_vectors, hash_times=hash_times)
         _, idx, ncand, _ = self.scan_tensors(query_vectors, keys, nkeys, k=k)
-        short = bool((ncand < k).any().item())
-        key_sets = keys_to_sets(keys, nkeys, self._hashing.key_mode) if (short and self.compat) else None
-        if key_sets is None:
-            key_sets = [()] * query_vectors.shape[0]
+        key_sets = {}
+        if self.compat:  # F7 needs the key SET (Python iteration order) of the queries with < k candidates only
+            short = torch.nonzero(ncand < k).view(-1)
+            if short.numel():
+                sets = keys_to_sets(keys[short], nkeys[short], self._hashing.key_mode)
+                key_sets = dict(zip(short.cpu().tolist(), sets))
         return self._to_lists(key_sets, idx, ncand, k)
 
     def query_with_keys(self, query_vectors, key_lists: Sequence[Sequence[int]], k=10):
