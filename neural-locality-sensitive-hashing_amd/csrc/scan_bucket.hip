@@ -1,20 +1,24 @@
-// Bucket-major candidate scan (algo NLSH_SCAN_BUCKET_MAJOR of nlsh_scan_topk).
+// Bucket-major candidate scan (algos NLSH_SCAN_BUCKET_MAJOR and NLSH_SCAN_BUCKET_TILED of nlsh_scan_topk).
 //
-// Same contract and arithmetic as the query-major kernel (scan_topk.hip; reference
-// nlsh/indexer.py:62-95), different schedule: when many queries of a batch probe the same buckets
-// (SIFT1M-shaped run: 10k queries x 10 probes over 5.8k buckets -> every corpus row is a candidate
-// of ~24 queries) the query-major kernel re-reads each row once per query and sits on the HBM
-// roofline.  Here the (query, probe) pairs are inverted into per-bucket query lists on the device
-// and ONE wavefront scores a row tile against a GROUP of up to QB=8 queries held in registers, so a
-// row is fetched ceil(m_b/QB) times instead of m_b times; the kernel moves from HBM-bound towards
-// VALU-bound (19 VALU per row-pair and query).
+// Same contract as the query-major kernel (scan_topk.hip; reference nlsh/indexer.py:62-95), different
+// schedule: when many queries of a batch probe the same buckets (SIFT1M-shaped run: 45k distinct
+// (query, bucket) pairs over 5k buckets -> every corpus row is a candidate of ~24 queries) the
+// query-major kernel re-reads each row once per query and sits on the HBM roofline.  Here the
+// (query, probe) pairs are inverted into per-bucket query lists on the device and a row tile is scored
+// against a GROUP of queries per fetch:
+//   bscan2 (wave-level):  one wavefront = (bucket segment, <= 8 queries in VGPRs); lanes span a row,
+//                         cross-lane DPP/permlane reduction per (row, query); same bits as query-major;
+//   bscan3 (LDS-tiled):   one workgroup = (256-row segment, <= 16 queries); every lane owns a row of each
+//                         tile, queries arrive as scalar loads, no cross-lane traffic, k-ordered fmaf chain
+//                         (bit-identical to the oracle), selection by bisection instead of insertion.
 //
 // Per batch, all on the caller's stream, no host round trip:
 //   bplan    thread/(query,probe): binary search key -> bucket; count pairs per bucket; C_q
 //   bscan    thread/bucket: block scan + one atomic per block -> disjoint pair/task ranges;
-//            task = (group of <= QB pairs, segment of <= seg_rows rows)
+//            task = (group of <= QB pairs, segment of <= seg rows), segment-major ids
 //   bscatter thread/(query,probe): claim a slot in the bucket's query list
-//   bscan2   wave/task: stream the segment once, keep QB best-64 lists, write partial top-k
+//   bprep    (tiled, cosine or d % 4 != 0 only) padded / pre-normalised copy of the queries
+//   bscan2 | bscan3: partial top-k per (task, query)
 //   bmerge   wave/query: merge the partial lists of its (probe, segment) pairs -> final top-k
 // Results do not depend on slot/task order: every list is merged with the (distance, id) comparator.
 #include "scan_common.h"

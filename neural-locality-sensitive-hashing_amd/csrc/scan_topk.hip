@@ -5,13 +5,14 @@
 // (:84-87; nlsh/data.py:99-109, 191-201), cat (:88), topk + .tolist() with a device sync per
 // query (:90-91).
 //
-// Two schedules share the arithmetic (scan_common.h), so their results are bit-identical:
-//   algo 0, QUERY-MAJOR (this file): one wavefront per (query, <= seg_rows candidates); every
-//     candidate row is fetched once per query that probes it.  Best when buckets are small and
-//     few queries share a bucket (balanced hash): a query's <= P buckets are walked by one wave.
-//   algo 1, BUCKET-MAJOR (scan_bucket.hip): one wavefront per (bucket segment, group of <= 8
-//     queries probing that bucket); a row tile is fetched once and scored against all queries of
-//     the group from registers, cutting HBM traffic by up to 8x when many queries share buckets.
+// Three schedules, one contract (selected by `algo`; Indexer.choose_algo picks per batch):
+//   0 QUERY-MAJOR (this file): one wavefront per (query, <= seg_rows candidates); every candidate row is
+//     fetched once per query that probes it: the HBM-roofline design.  Best when buckets are small and few
+//     queries share a bucket (balanced hash): a query's <= P buckets are walked by one wave.
+//   1 BUCKET-MAJOR, wave level (scan_bucket.hip): one wavefront per (bucket segment, <= 8 queries held in
+//     registers); same lane-partial + DPP tree arithmetic as 0, so 0 and 1 are bit-identical.
+//   2 BUCKET-MAJOR, LDS-tiled (scan_bucket.hip): one workgroup per (256-row segment, <= 16 queries), lane
+//     owns a row, k-ordered fmaf chain (bit-identical to the oracle), up to 16x less HBM traffic.
 //
 // gfx950 mapping of the query-major kernel (HBM-bound: 4*d bytes, 3*d flop per candidate)
 //   * the corpus is bucket-contiguous (nlsh_gather_rows), so a query's candidate list is a

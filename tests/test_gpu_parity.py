@@ -114,9 +114,6 @@ def test_multiprobe_keys_match_oracle_sampler():
             for r in range(300):
                 assert np.array_equal(kd[r, :no[r]], ko[r, :no[r]])
             assert np.all(no[n_multi:] == 1)                 # F6: trailing rows single-probe
-    # sampled probes behave like Bernoulli(p): mean bit frequency ~ p (statistical, 300x9 draws per bit)
-    hashing = make_hashing(d, hidden, H, Ws, bs, compat=False)
-    _, probs, _ = hashing.forward_device(dev(x))
 
 
 def test_indexer_hash_batching_rule_g3():

@@ -143,3 +143,47 @@ def test_g7_sift_small_end_to_end():
     assert agree >= 0.97 * meta["Q"]
     rec = oracle.calculate_recall(list(g["ground_truth"]), res, np.mean)
     assert abs(rec - meta["mean_recall"]) < 0.01
+
+
+def test_philox4x32_10_known_answers():
+    """Random123 known-answer vectors for Philox4x32-10 (the multi-probe sampler's generator; the HIP
+    encoder's keys are compared bit-for-bit with this stream in the GPU suite)."""
+    kat = [((0, 0, 0, 0), 0, (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, 0xffffffffffffffff, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0x299f31d0 << 32) | 0xa4093822,
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        assert tuple(oracle.philox(key, *ctr)) == want
+
+
+def test_sampled_probes_track_probabilities():
+    """Probes 1.. are Bernoulli(p) draws keyed by (seed, row, probe, word): their bit frequencies follow p."""
+    H, rows, probes = 12, 64, 200
+    rng = np.random.default_rng(5)
+    p01 = rng.uniform(0.02, 0.98, size=(rows, H)).astype(np.float32)
+    freq = np.zeros((rows, H))
+    for r in range(rows):
+        for j in range(1, probes + 1):
+            for w in range((H + 3) // 4):
+                u = [np.float32(v >> 8) * np.float32(1.0 / 16777216.0) for v in oracle.philox(99, r, 0, j, w)]
+                for e in range(4):
+                    if 4 * w + e < H:
+                        freq[r, 4 * w + e] += u[e] < p01[r, 4 * w + e]
+    err = np.abs(freq / probes - p01)
+    assert err.mean() < 0.03 and err.max() < 0.15      # sd <= 0.035 per cell at 200 draws
+    # and the key stream itself is those draws: probe j of row r packs the same bits MSB-first
+    keys, n = oracle.row_keys(p01, 8, "full", seed=99, n_multi_rows=rows)
+    for r in range(4):
+        seen = []
+        for j in range(8):
+            code = 0
+            for h in range(H):
+                if j == 0:
+                    bit = p01[r, h] > 0.5
+                else:
+                    u = np.float32(oracle.philox(99, r, 0, j, h >> 2)[h & 3] >> 8) * np.float32(1.0 / 16777216.0)
+                    bit = u < p01[r, h]
+                code = (code << 1) | int(bit)
+            if code not in seen:
+                seen.append(code)
+        assert list(keys[r, :n[r]]) == seen
