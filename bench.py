@@ -8,8 +8,9 @@ A "step" = one pass of the hot path over the whole query batch (BASELINE.json co
 SIFT1M-shaped, 1M x 128-d corpus, 10k queries, 16-bit hash, k=10, hash_times=10):
 encode_hash (MLP on fp32 MFMA + bits + multi-probe keys) -> plan -> scan_topk -> merge, all
 device-resident (inputs in HBM before the timed region, results left in HBM).  N>1: corpus rows
-sharded over the ranks, every rank answers all queries over its shard, one all-gather (RCCL) of the
-per-rank top-k + merge per step ("strong" scaling: total work fixed).
+buckets sharded over the ranks (whole buckets per rank, one build-time all-to-all; `--shard rows` keeps
+contiguous row ranges instead), every rank answers all queries over its shard, one all-gather (RCCL) of
+the per-rank top-k + merge per step ("strong" scaling: total work fixed).
 
 Prints ONE JSON line (rank 0).  `roofline` is the scan kernel's algorithmic bytes (4*d*sum C_q,
 SURVEY.md §8(d)) over its HIP-event-measured duration; `cpu_baseline` is the CPU oracle timed on
@@ -33,6 +34,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (155 TF measured)
 
 
 def parse():
@@ -49,6 +51,8 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--hash-times", type=int, default=10)
     ap.add_argument("--seg-rows", type=int, default=0)
+    ap.add_argument("--shard", default="buckets", choices=["buckets", "rows"],
+                    help="N>1 partition of the corpus: whole buckets per rank (default) or contiguous row ranges")
     ap.add_argument("--algo", default=None, choices=["query", "bucket", "tiled"], help="force a scan schedule (default: auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--random-init", action="store_true", help="ignore the learned-hash checkpoint")
@@ -76,7 +80,7 @@ def main():
 
     from nlsh_amd import _capi, synth
     from nlsh_amd.data import Glove, SIFT, brute_force_topk
-    from nlsh_amd.distributed import gather_and_merge, shard_range
+    from nlsh_amd.distributed import ShardedIndexer, gather_and_merge, shard_range
     from nlsh_amd.encoders import MultiLayerRelu
     from nlsh_amd.hashings import MultivariateBernoulli
     from nlsh_amd.indexer import Indexer
@@ -120,15 +124,20 @@ def main():
     queries = torch.from_numpy(queries_h).to(dev)
     torch.cuda.synchronize()
     t0 = time.time()
-    indexer = Indexer(hashing, shard, SIFT.distance if metric == "l2" else Glove.distance, compat=H <= 16, id_base=lo,
-                      seg_rows=args.seg_rows, algo=args.algo, stats_scale=world)
+    distance = SIFT.distance if metric == "l2" else Glove.distance
+    if world > 1:   # build-time exchange (all-gather of keys + all-to-all of rows for --shard buckets) is inside build_s
+        indexer = ShardedIndexer(hashing, shard, distance, id_base=lo, shard=args.shard, compat=H <= 16,
+                                 seg_rows=args.seg_rows, algo=args.algo).local
+    else:
+        indexer = Indexer(hashing, shard, distance, compat=H <= 16, seg_rows=args.seg_rows, algo=args.algo)
     torch.cuda.synchronize()
     build_s = time.time() - t0
     stats = indexer.bucket_stats()
 
     steps, warmup = args.steps, args.warmup
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    for a, b in ev:  # instantiate the hipEvent handles
+    ev_x = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in ev + ev_x:  # instantiate the hipEvent handles
         a.record(); b.record()
 
     def step(i, check=False, events=None):
@@ -136,7 +145,11 @@ def main():
         dist_, idx_, nc_, k64 = indexer.query_tensors(queries, k=k, hash_times=P, seed=seed, want_keys=world > 1,
                                                        check=check, events=events)
         if world > 1:
+            if events is not None:
+                ev_x[i][0].record()
             dist_, idx_, nc_ = gather_and_merge(k64, nc_, k)
+            if events is not None:
+                ev_x[i][1].record()
         return dist_, idx_, nc_
 
     step(-1, check=True)  # sizes the segment table (may retry once); untimed
@@ -177,6 +190,32 @@ def main():
         ids_api, nc_api = indexer.query(queries, k=k, hash_times=P)
         api_qps = Q / (time.perf_counter() - t0)
 
+    # encoder (MFMA) utilisation on this rank's corpus rows, and the box's measured HBM copy rate next to the spec peak
+    enc = None
+    if world == 1:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        hashing.hash_device(shard, n=1)
+        e0.record()
+        for _ in range(5):
+            hashing.hash_device(shard, n=1)
+        e1.record()
+        torch.cuda.synchronize()
+        enc_ms = e0.elapsed_time(e1) / 5
+        flops = 2.0 * (d * 256 + 256 * 256 + 256 * H) * shard.shape[0]
+        enc = {"kernel": "encode_hash_kernel (fp32 MFMA 32x32x2, fused bits + keys)", "rows": int(shard.shape[0]), "ms": enc_ms,
+               "tflops": flops / (enc_ms * 1e-3) / 1e12, "peak_tflops": MFMA_F32_PEAK_TFLOPS,
+               "mfma_util": flops / (enc_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}
+        src = torch.empty((1 << 28,), dtype=torch.float32, device=dev)      # 1 GiB read + 1 GiB written per copy
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 2.0 * src.numel() * 4 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+
     # HBM traffic per launch: PMC numbers cannot be collected from inside the process; they come from
     # the committed rocprofv3 --pmc passes of this round (profiles/traffic_r01.json) when the workload matches.
     traffic = None
@@ -205,7 +244,9 @@ def main():
             "recall_at_10": recall,
             "config": {"workload": f"{wl['cfg']}, N={N} d={d} Q={Q} H={H} k={k} hash_times={P}",
                        "hash": hash_desc,
-                       "parallelism": f"corpus rows sharded x{world}, all-gather top-k" if world > 1 else "single GPU",
+                       "parallelism": (f"corpus {args.shard} sharded x{world} ({indexer._candidate_vectors_gpu.shape[0]} rows on rank 0), "
+                                       f"all-gather of per-shard top-k + merge: {float(np.mean([a.elapsed_time(b) for a, b in ev_x])):.4f} ms/step"
+                                       ) if world > 1 else "single GPU",
                        "n_buckets": stats["n_indexes"], "bucket_mean": stats["mean"], "bucket_median": stats["median"],
                        "bucket_max": stats["max"], "mean_candidates_per_query": mean_c,
                        "index_build_s": build_s, "api_list_qps": api_qps},
@@ -215,6 +256,9 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms,
                          "sum_candidates_per_launch": sum_c_local, "tasks_per_launch": n_tasks},
         }
+        if enc is not None:
+            result["encoder"] = enc
+            result["roofline"]["hbm_copy_measured_GBps"] = copy_gbps
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, corpus_h, queries_h, Ws, bs, indexer, hashing, queries, steps, metric)
         print(json.dumps(result), flush=True)
@@ -251,11 +295,24 @@ def cpu_baseline(args, corpus_h, queries_h, Ws, bs, indexer, hashing, queries, s
     th, ts = run(probe)
     per_q = (th + ts) / probe
     sample = int(min(Q, max(probe, args.cpu_seconds / max(per_q, 1e-9))))
-    th, ts = run(sample)
-    return {"value": sample / (th + ts), "unit": "queries/s", "cores": threads, "kind": "port",
-            "sample": f"first {sample} of {Q} queries, same keys/candidate sets as the GPU run; "
-                      f"hash {th:.3f}s (numpy BLAS) + scan {ts:.3f}s (C, OpenMP x{threads})",
-            "host_cpu_count": os.cpu_count()}
+    passes, th, ts = 0, 0.0, 0.0
+    while passes == 0 or (th + ts < args.cpu_seconds and passes < 64):     # bounded: ~cpu_seconds of CPU work
+        a, b = run(sample)
+        th, ts, passes = th + a, ts + b, passes + 1
+    out = {"value": sample * passes / (th + ts), "unit": "queries/s", "cores": threads, "kind": "port",
+           "sample": f"first {sample} of {Q} queries x {passes} passes, same keys/candidate sets as the GPU run; "
+                     f"hash {th:.3f}s (numpy BLAS) + scan {ts:.3f}s (C, OpenMP x{threads})",
+           "host_cpu_count": os.cpu_count()}
+    # the same restatement on ONE thread (the reference's per-query loop is single-threaded Python over torch ops)
+    oracle.set_num_threads(1)
+    try:
+        one = max(16, min(sample, int(3.0 / max(per_q * threads * 0.5, 1e-9))))
+        t0 = time.perf_counter()
+        oracle.query_batch(corpus_h, perm, uniq, offs, queries_h[:one], kh[:one], nh[:one], k, metric)
+        out["scan_only_1_thread_qps"] = one / (time.perf_counter() - t0)
+    finally:
+        oracle.set_num_threads(threads)
+    return out
 
 
 if __name__ == "__main__":

@@ -108,6 +108,15 @@ size_t nlsh_build_csr_workspace(int64_t n);
 int nlsh_build_csr(const int32_t *keys, int64_t n, int32_t *perm, int32_t *uniq_keys, int32_t *offsets,
                    int32_t *n_buckets, void *workspace, size_t workspace_bytes, nlsh_stream_t stream);
 
+/* Schedule order of the buckets for the bucket-major scans: order_out [dev] int32 [n_buckets] = bucket
+ * indices by DESCENDING size (ties: ascending index), from offsets [dev] [n_buckets + 1].  Static per index:
+ * nlsh_scan_topk numbers its (bucket segment, query group) tasks in this order, so the heavy tasks of the big
+ * buckets are dispatched first and the launch does not end on a tail of late-started long tasks.  No reference
+ * counterpart (the reference walks `for key in index_keys`, nlsh/indexer.py:66); changes speed, never results. */
+size_t nlsh_bucket_order_workspace(int64_t n_buckets);
+int nlsh_bucket_order(const int32_t *offsets, int64_t n_buckets, int32_t *order_out, void *workspace,
+                      size_t workspace_bytes, nlsh_stream_t stream);
+
 /* Re-order the corpus bucket-contiguously: sorted[i, :] = corpus[perm[i], :], zero padded to
  * dst_stride floats (dst_stride % 4 == 0, >= d).  Replaces the per-(query,key) index_select
  * gather of nlsh/indexer.py:77-82 by a one-time permutation.  inv_norm (nullable) [n] receives
@@ -125,8 +134,8 @@ int nlsh_gather_rows(const float *corpus, int64_t src_stride, int d, const int32
 size_t nlsh_scan_workspace(int64_t Q, int P, int k, int64_t max_tasks, int64_t n_buckets, int d);
 
 /* corpus_sorted [dev] fp32 [N, row_stride] bucket-contiguous (nlsh_gather_rows), gid [dev] [N],
- * uniq_keys [dev] [n_buckets] ascending, offsets [dev] [n_buckets+1], inv_norm [dev] [N] (cosine
- * only), queries [dev] [Q, d] stride q_stride, qkeys [dev] [Q, P] with nkeys [dev] [Q] valid slots
+ * uniq_keys [dev] [n_buckets] ascending, offsets [dev] [n_buckets+1], bucket_order (nullable) [dev]
+ * [n_buckets] from nlsh_bucket_order (NULL = CSR order), inv_norm [dev] [N] (cosine only), queries [dev] [Q, d] stride q_stride, qkeys [dev] [Q, P] with nkeys [dev] [Q] valid slots
  * (distinct keys; unknown keys are empty buckets, never an error: indexer.py:61,68).
  * Outputs [dev]: out_dist [Q, k] ascending, +inf padded; out_idx [Q, k] global row ids, -1 padded;
  * out_keys (nullable) [Q, k] the 64-bit sort keys (monotone(dist) << 32 | id; ~0 padded) used by
@@ -139,7 +148,7 @@ size_t nlsh_scan_workspace(int64_t Q, int P, int k, int64_t max_tasks, int64_t n
  * after the scan kernel, so a caller can time the HBM-bound kernel alone (bench.py roofline).
  * Limits: d <= NLSH_MAX_DIM, k <= NLSH_MAX_K, P <= NLSH_MAX_PROBES. */
 int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, int d, const int32_t *gid,
-                   const int32_t *uniq_keys, const int32_t *offsets, int32_t n_buckets,
+                   const int32_t *uniq_keys, const int32_t *offsets, const int32_t *bucket_order, int32_t n_buckets,
                    const float *inv_norm, const float *queries, int64_t q_stride, int64_t Q,
                    const int32_t *qkeys, const int32_t *nkeys, int P, int k, int metric, int algo, int seg_rows,
                    float *out_dist, int32_t *out_idx, uint64_t *out_keys, int32_t *out_ncand,

@@ -80,7 +80,35 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *corpus, l
     }
 }
 
+// bucket sizes as sort keys + identity values for the size-descending schedule order
+__global__ void bucket_sizes_kernel(const int32_t *offsets, long long nb, uint32_t *sizes, int32_t *idx) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += (long long)gridDim.x * blockDim.x) {
+        sizes[i] = (uint32_t)(offsets[i + 1] - offsets[i]);
+        idx[i] = (int32_t)i;
+    }
+}
+
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct OrderWs {
+    size_t sizes, sorted_sizes, idx, tmp, tmp_bytes, total;
+};
+
+static int order_layout(long long nb, OrderWs *w, hipStream_t s) {
+    const size_t n4 = align_up((size_t)(nb > 0 ? nb : 1) * 4);
+    size_t t_sort = 0;
+    uint32_t *nulk = nullptr;
+    int32_t *nulv = nullptr;
+    hipError_t e = rocprim::radix_sort_pairs_desc(nullptr, t_sort, nulk, nulk, nulv, nulv, (size_t)nb, 0, 32, s);
+    if (e != hipSuccess) { set_error("rocprim::radix_sort_pairs_desc size query: %s", hipGetErrorString(e)); return NLSH_E_HIP; }
+    w->sizes = 0;
+    w->sorted_sizes = n4;
+    w->idx = 2 * n4;
+    w->tmp = 3 * n4;
+    w->tmp_bytes = align_up(t_sort);
+    w->total = w->tmp + w->tmp_bytes;
+    return NLSH_OK;
+}
 
 struct CsrWs {
     size_t sk, iota, flags, rank, tmp, tmp_bytes, total;
@@ -144,6 +172,36 @@ extern "C" int nlsh_build_csr(const int32_t *keys, int64_t n, int32_t *perm, int
     tb = w.tmp_bytes;
     NLSH_CHECK_HIP(rocprim::inclusive_scan(tmp, tb, flags, rank, (size_t)n, rocprim::plus<int32_t>(), s));
     hipLaunchKernelGGL(emit_buckets_kernel, dim3(grid), dim3(256), 0, s, sk, flags, rank, (long long)n, uniq_keys, offsets, n_buckets);
+    NLSH_CHECK_HIP(hipGetLastError());
+    return NLSH_OK;
+}
+
+extern "C" size_t nlsh_bucket_order_workspace(int64_t n_buckets) {
+    if (n_buckets < 0) { set_error("bucket_order_workspace: n_buckets=%lld", (long long)n_buckets); return 0; }
+    OrderWs w;
+    if (order_layout(n_buckets, &w, nullptr) != NLSH_OK) return 0;
+    return w.total;
+}
+
+extern "C" int nlsh_bucket_order(const int32_t *offsets, int64_t n_buckets, int32_t *order_out, void *workspace,
+                                 size_t workspace_bytes, nlsh_stream_t stream) {
+    NLSH_REQUIRE(n_buckets >= 0 && n_buckets < (1ll << 31), NLSH_E_INVALID, "bucket_order: n_buckets=%lld", (long long)n_buckets);
+    if (n_buckets == 0) return NLSH_OK;
+    NLSH_REQUIRE(offsets && order_out && workspace, NLSH_E_INVALID, "bucket_order: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    OrderWs w;
+    int rc = order_layout(n_buckets, &w, s);
+    if (rc != NLSH_OK) return rc;
+    NLSH_REQUIRE(workspace_bytes >= w.total, NLSH_E_WORKSPACE, "bucket_order: workspace %zu < %zu", workspace_bytes, w.total);
+    char *base = (char *)workspace;
+    uint32_t *sizes = (uint32_t *)(base + w.sizes), *sorted_sizes = (uint32_t *)(base + w.sorted_sizes);
+    int32_t *idx = (int32_t *)(base + w.idx);
+    int grid = (int)((n_buckets + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(bucket_sizes_kernel, dim3(grid), dim3(256), 0, s, offsets, (long long)n_buckets, sizes, idx);
+    size_t tb = w.tmp_bytes;
+    // stable: buckets of equal size keep ascending key order -> the order is a pure function of the index
+    NLSH_CHECK_HIP(rocprim::radix_sort_pairs_desc(base + w.tmp, tb, sizes, sorted_sizes, idx, order_out, (size_t)n_buckets, 0, 32, s));
     NLSH_CHECK_HIP(hipGetLastError());
     return NLSH_OK;
 }

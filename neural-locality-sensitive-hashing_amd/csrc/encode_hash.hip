@@ -5,8 +5,12 @@
 // .cpu().numpy() -> nlsh/utils.pyx:6-32 (binarr_to_int, set()).  Nothing leaves the device.
 //
 // gfx950 mapping
-//   * one workgroup (4 wavefronts, 256 threads) owns M = 32*RT rows; their activations never
-//     leave LDS (two ping-pong [M][S] fp32 images, 133 KB at width 256);
+//   * one workgroup (NW = 8 wavefronts, 512 threads) owns M = 32*RT rows; their activations never
+//     leave LDS (two ping-pong [M][S] fp32 images, 133 KB at width 256, so ONE workgroup per CU: the
+//     two wavefronts per SIMD are what overlaps one wave's LDS/L2 waits, write-back and epilogue VALU
+//     work with the other's MFMA chain -- with 4 waves a workgroup took 42 us, MFMA-busy for 24);
+//   * a wavefront owns one 32-column tile of a hidden layer (8 tiles at width 256) for all RT row tiles,
+//     so a B fragment is fetched once per RT MFMAs;
 //   * every Linear layer is an fp32 MFMA chain, v_mfma_f32_32x32x2_f32: exact fp32, result is
 //     bit-for-bit a k-ascending fmaf chain (guide §3 "FP32-input MFMA"), which is what the oracle
 //     computes -> z is bit-exact against oracle_mlp_forward;
@@ -65,9 +69,18 @@ __device__ __forceinline__ void philox4x32_10(unsigned long long seed, uint32_t 
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-template <int RT>
-__global__ __launch_bounds__(256) void encode_hash_kernel(EncArgs a) {
+// Diagnostic build only (make EXTRA=-DNLSH_ENC_TRACE, tools/enc_trace.py): thread 0 of every workgroup
+// leaves the 100 MHz wall_clock64 stamp of each phase boundary in the first floats of its z_out rows.
+#ifdef NLSH_ENC_TRACE
+#define ENC_STAMP(i) do { if (tid == 0) stamp[i] = wall_clock64(); } while (0)
+#else
+#define ENC_STAMP(i) do { } while (0)
+#endif
+
+template <int RT, int NW>
+__global__ __launch_bounds__(NW * 64) void encode_hash_kernel(EncArgs a) {
     constexpr int M = 32 * RT;
+    constexpr int NTH = NW * 64;
     extern __shared__ float4 smem4[];
     float *smem = reinterpret_cast<float *>(smem4);
     const int S = a.S;
@@ -80,6 +93,10 @@ __global__ __launch_bounds__(256) void encode_hash_kernel(EncArgs a) {
     const int lr = lane & 31;   // row (A) / column (B, C) inside a 32x32 tile
     const int lh = lane >> 5;   // k parity (A, B) / row-quad select (C)
     const long long row_base = (long long)blockIdx.x * M;
+#ifdef NLSH_ENC_TRACE
+    unsigned long long stamp[12];
+#endif
+    ENC_STAMP(0);
 
     // ---- stage the input rows (zero padded to Kp, zero rows past n) in the de-interleaved layout
     {
@@ -91,18 +108,18 @@ __global__ __launch_bounds__(256) void encode_hash_kernel(EncArgs a) {
             const int Kq = Kp0 >> 2, total = M * Kq;
             const float4 *x4 = reinterpret_cast<const float4 *>(a.x);
             const long long xs4 = a.x_stride >> 2;
-            for (int e0 = 0; e0 < total; e0 += 256 * 8) {
+            for (int e0 = 0; e0 < total; e0 += NTH * 8) {
                 float4 v[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const int e = e0 + i * 256 + tid;
+                    const int e = e0 + i * NTH + tid;
                     const int r = e / Kq, c4 = e - r * Kq;
                     const long long grow = row_base + r;
                     v[i] = (e < total && grow < a.n && 4 * c4 < K0) ? x4[grow * xs4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const int e = e0 + i * 256 + tid;
+                    const int e = e0 + i * NTH + tid;
                     if (e < total) {
                         const int r = e / Kq, c4 = e - r * Kq;
                         float *dst = in + r * S + ((4 * c4) & ~7) + ((c4 & 1) << 1);  // pos(4*c4 + j) = base + {0,4,1,5}
@@ -111,7 +128,7 @@ __global__ __launch_bounds__(256) void encode_hash_kernel(EncArgs a) {
                 }
             }
         } else {
-            for (int e = tid; e < M * Kp0; e += 256) {
+            for (int e = tid; e < M * Kp0; e += NTH) {
                 int r = e / Kp0, k = e - r * Kp0;
                 long long grow = row_base + r;
                 float v = (grow < a.n && k < K0) ? a.x[grow * a.x_stride + k] : 0.0f;
@@ -120,6 +137,7 @@ __global__ __launch_bounds__(256) void encode_hash_kernel(EncArgs a) {
         }
     }
     __syncthreads();
+    ENC_STAMP(1);
 
     for (int l = 0; l < a.n_layers; ++l) {
         const LayerDesc L = a.L[l];
@@ -130,69 +148,91 @@ __global__ __launch_bounds__(256) void encode_hash_kernel(EncArgs a) {
         if (!last) {
             const int NT = L.Np >> 5;
             const int ncol_keep = a.L[l + 1].Kp;  // columns the next layer reads (>= N, zero padded)
-            for (int nt0 = wave; nt0 < NT; nt0 += 8) {
-                const bool has2 = (nt0 + 4) < NT;
-                const int nt1 = has2 ? nt0 + 4 : nt0;
-                f32x16 acc[RT][2];
+            for (int nt0 = wave; nt0 < NT; nt0 += NW) {
+                f32x16 acc[RT];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                    for (int g = 0; g < 2; ++g)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) acc[rt][g][i] = 0.0f;
+                    for (int i = 0; i < 16; ++i) acc[rt][i] = 0.0f;
                 const float4 *w0 = Wp + (size_t)nt0 * nch * 64 + lane;
-                const float4 *w1 = Wp + (size_t)nt1 * nch * 64 + lane;
                 const float *arow = in + (size_t)lr * S + 4 * lh;
-                float4 bn0 = w0[0], bn1 = w1[0];
+                // B fragments ride a ring of four registers, fetched THREE k-chunks (24 MFMAs) ahead of their use.
+                // The ring is indexed statically (main loop unrolled by 4, branch-free: indices past the end are
+                // clamped and their data unused), so neither a register rotation nor a control-flow join makes
+                // the compiler wait for the youngest load; A fragments (LDS) are fetched one chunk ahead.
+                float4 B[4];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) B[j] = w0[(size_t)min(j, nch - 1) * 64];
                 float4 an[RT];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) an[rt] = *reinterpret_cast<const float4 *>(arow + (size_t)rt * 32 * S);
-                for (int c = 0; c < nch; ++c) {
-                    float4 b0 = bn0, b1 = bn1;
-                    float4 av[RT];
+                const int nch4 = nch & ~3;
+                for (int c = 0; c < nch4; c += 4) {
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) av[rt] = an[rt];
-                    if (c + 1 < nch) {
-                        bn0 = w0[(size_t)(c + 1) * 64];
-                        bn1 = w1[(size_t)(c + 1) * 64];
+                    for (int j = 0; j < 4; ++j) {
+                        const int cc = c + j;
+                        B[(j + 3) & 3] = w0[(size_t)min(cc + 3, nch - 1) * 64];
+                        float4 av[RT];
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) av[rt] = an[rt];
 #pragma unroll
                         for (int rt = 0; rt < RT; ++rt)
-                            an[rt] = *reinterpret_cast<const float4 *>(arow + (size_t)rt * 32 * S + (c + 1) * 8);
+                            an[rt] = *reinterpret_cast<const float4 *>(arow + (size_t)rt * 32 * S + min(cc + 1, nch - 1) * 8);
+                        // keep the fetches HERE: the machine scheduler otherwise sinks them next to their use
+                        // (seen: load; s_waitcnt vmcnt(0); mfma -- an exposed L2 round trip every four chunks)
+                        __builtin_amdgcn_sched_barrier(0);
+                        const float bb0[4] = {B[j].x, B[j].y, B[j].z, B[j].w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                            for (int rt = 0; rt < RT; ++rt) {
+                                const float aa = i == 0 ? av[rt].x : i == 1 ? av[rt].y : i == 2 ? av[rt].z : av[rt].w;
+                                acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa, bb0[i], acc[rt], 0, 0, 0);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    const float bb0[4] = {b0.x, b0.y, b0.z, b0.w};
-                    const float bb1[4] = {b1.x, b1.y, b1.z, b1.w};
+                }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                for (int j = 0; j < 3; ++j) {  // the nch % 4 trailing chunks sit in ring slots 0..2
+                    const int cc = nch4 + j;
+                    if (cc < nch) {
+                        float4 av[RT];
 #pragma unroll
-                        for (int rt = 0; rt < RT; ++rt) {
-                            const float aa = i == 0 ? av[rt].x : i == 1 ? av[rt].y : i == 2 ? av[rt].z : av[rt].w;
-                            acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa, bb0[i], acc[rt][0], 0, 0, 0);
-                            if (has2) acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa, bb1[i], acc[rt][1], 0, 0, 0);
+                        for (int rt = 0; rt < RT; ++rt) av[rt] = an[rt];
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+                            an[rt] = *reinterpret_cast<const float4 *>(arow + (size_t)rt * 32 * S + min(cc + 1, nch - 1) * 8);
+                        const float bb0[4] = {B[j].x, B[j].y, B[j].z, B[j].w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                            for (int rt = 0; rt < RT; ++rt) {
+                                const float aa = i == 0 ? av[rt].x : i == 1 ? av[rt].y : i == 2 ? av[rt].z : av[rt].w;
+                                acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa, bb0[i], acc[rt], 0, 0, 0);
+                            }
                         }
                     }
                 }
                 // write-back: bias + ReLU (encoders.py:19-20), C/D map: col = lane&31,
                 // row = (i&3) + 8*(i>>2) + 4*(lane>>5)
+                const int col = nt0 * 32 + lr;
+                if (col < ncol_keep) {
+                    const float bias = Bp[col];
+                    const int pc = pos(col);
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    if (g == 1 && !has2) break;
-                    const int col = (g == 0 ? nt0 : nt1) * 32 + lr;
-                    if (col < ncol_keep) {
-                        const float bias = Bp[col];
-                        const int pc = pos(col);
+                    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) {
-                                const int row = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-                                float v = acc[rt][g][i] + bias;
-                                out[(size_t)row * S + pc] = v > 0.0f ? v : 0.0f;
-                            }
-                    }
+                        for (int i = 0; i < 16; ++i) {
+                            const int row = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+                            float v = acc[rt][i] + bias;
+                            out[(size_t)row * S + pc] = v > 0.0f ? v : 0.0f;
+                        }
                 }
             }
             __syncthreads();
             float *t = in; in = out; out = t;
+            ENC_STAMP(2 + (l < 4 ? l : 4));
         } else {
             // output layer: H <= 32 -> one column tile; one row tile per wavefront
             if (wave < RT) {
@@ -201,18 +241,37 @@ __global__ __launch_bounds__(256) void encode_hash_kernel(EncArgs a) {
                 for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
                 const float4 *w0 = Wp + lane;
                 const float *arow = in + (size_t)(wave * 32 + lr) * S + 4 * lh;
-                float4 bn0 = w0[0];
+                float4 B[4];  // same ring as the hidden layers
+#pragma unroll
+                for (int j = 0; j < 3; ++j) B[j] = w0[(size_t)min(j, nch - 1) * 64];
                 float4 an = *reinterpret_cast<const float4 *>(arow);
-                for (int c = 0; c < nch; ++c) {
-                    float4 b0 = bn0, av = an;
-                    if (c + 1 < nch) {
-                        bn0 = w0[(size_t)(c + 1) * 64];
-                        an = *reinterpret_cast<const float4 *>(arow + (c + 1) * 8);
+                const int nch4 = nch & ~3;
+                for (int c = 0; c < nch4; c += 4) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int cc = c + j;
+                        B[(j + 3) & 3] = w0[(size_t)min(cc + 3, nch - 1) * 64];
+                        const float4 av = an;
+                        an = *reinterpret_cast<const float4 *>(arow + min(cc + 1, nch - 1) * 8);
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, B[j].x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, B[j].y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, B[j].z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, B[j].w, acc, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int cc = nch4 + j;
+                    if (cc < nch) {
+                        const float4 av = an;
+                        an = *reinterpret_cast<const float4 *>(arow + min(cc + 1, nch - 1) * 8);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, B[j].x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, B[j].y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, B[j].z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, B[j].w, acc, 0, 0, 0);
+                    }
                 }
                 const float bias = Bp[lr];
 #pragma unroll
@@ -225,11 +284,12 @@ __global__ __launch_bounds__(256) void encode_hash_kernel(EncArgs a) {
         }
     }
 
+    ENC_STAMP(7);
     // ---- epilogue.  `out` holds z [M][33]; `in` is free.
     const int H = a.H;
     float *zbuf = out;
     float *pbuf = in;  // Bernoulli probability [M][33]
-    for (int e = tid; e < M * H; e += 256) {
+    for (int e = tid; e < M * H; e += NTH) {
         int r = e / H, h = e - r * H;
         long long grow = row_base + r;
         float z = zbuf[r * 33 + h];
@@ -248,9 +308,10 @@ __global__ __launch_bounds__(256) void encode_hash_kernel(EncArgs a) {
         }
     }
     __syncthreads();
+    ENC_STAMP(8);
     int32_t *kbuf = reinterpret_cast<int32_t *>(out);  // [M][n_probes]; z is dead now
     const int NP = a.n_probes;
-    for (int e = tid; e < M * NP; e += 256) {
+    for (int e = tid; e < M * NP; e += NTH) {
         int r = e / NP, j = e - r * NP;
         long long grow = row_base + r;
         if (grow >= a.n || (j > 0 && grow >= a.n_multi_rows)) continue;
@@ -274,6 +335,7 @@ __global__ __launch_bounds__(256) void encode_hash_kernel(EncArgs a) {
         if (j == 0 && a.code_out) a.code_out[grow] = code;
     }
     __syncthreads();
+    ENC_STAMP(9);
     if (tid < M) {
         const int r = tid;
         long long grow = row_base + r;
@@ -290,6 +352,11 @@ __global__ __launch_bounds__(256) void encode_hash_kernel(EncArgs a) {
             a.nkeys_out[grow] = cnt;
         }
     }
+#ifdef NLSH_ENC_TRACE
+    ENC_STAMP(10);
+    if (tid == 0 && a.z_out && row_base + M <= a.n)
+        for (int i = 0; i <= 10; ++i) a.z_out[row_base * H + i] = (float)(stamp[i] - stamp[0]);
+#endif
 }
 
 // packed[w_off + ((nt*nch + c)*64 + lane)*4 + i] = W[nt*32 + (lane&31)][8c + 2i + (lane>>5)]
@@ -423,15 +490,15 @@ extern "C" int nlsh_encode_hash(const float *x, int64_t n, int64_t x_stride, int
     const size_t lds_limit = 160 * 1024;
     if ((size_t)2 * 64 * a.S * 4 <= lds_limit) {  // (32-row tiles for small batches measured slower: 0.775 vs 0.762 ms/step)
         size_t lds = (size_t)2 * 64 * a.S * 4;
-        NLSH_CHECK_HIP(hipFuncSetAttribute((const void *)encode_hash_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        NLSH_CHECK_HIP(hipFuncSetAttribute((const void *)encode_hash_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         long long grid = (n + 63) / 64;
-        hipLaunchKernelGGL(encode_hash_kernel<2>, dim3((unsigned)grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((encode_hash_kernel<2, 8>), dim3((unsigned)grid), dim3(512), lds, s, a);
     } else {
         size_t lds = (size_t)2 * 32 * a.S * 4;
         NLSH_REQUIRE(lds <= lds_limit, NLSH_E_UNSUPPORTED, "encode_hash: width %d needs %zu B of LDS", maxKp, lds);
-        NLSH_CHECK_HIP(hipFuncSetAttribute((const void *)encode_hash_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        NLSH_CHECK_HIP(hipFuncSetAttribute((const void *)encode_hash_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         long long grid = (n + 31) / 32;
-        hipLaunchKernelGGL(encode_hash_kernel<1>, dim3((unsigned)grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((encode_hash_kernel<1, 8>), dim3((unsigned)grid), dim3(512), lds, s, a);
     }
     NLSH_CHECK_HIP(hipGetLastError());
     return NLSH_OK;

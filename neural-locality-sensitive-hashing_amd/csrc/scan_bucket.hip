@@ -23,6 +23,34 @@
 // Results do not depend on slot/task order: every list is merged with the (distance, id) comparator.
 #include "scan_common.h"
 
+// Diagnostic build only (make EXTRA=-DNLSH_SCAN_TRACE, tools/scan_trace.py): wave 0 of every bscan3 workgroup
+// leaves its phase durations (100 MHz wall_clock64 ticks) in g_scan_trace; the shipped library has neither.
+#ifdef NLSH_SCAN_TRACE
+#define NLSH_TRACE_SLOTS (1 << 16)
+__device__ float g_scan_trace[NLSH_TRACE_SLOTS * 8];
+extern "C" int nlsh_debug_scan_trace(float *host, int n_floats) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_scan_trace), (size_t)n_floats * 4);
+}
+#define SCAN_NOW() wall_clock64()
+#else
+#define SCAN_NOW() 0ull
+#endif
+
+// 1 = branch-free k-block bodies specialised on (queries, tiles) per wave with hand-placed double buffering
+// (kblock_compute); measured slower at full size than the guarded generic loop (0.434 vs 0.417 ms: 137 VGPRs ->
+// 3 waves/SIMD instead of 4, 16 loop bodies in the instruction cache), faster on small shards (0.084 vs 0.089)
+#ifndef NLSH_KBLOCK_SPECIALISED
+#define NLSH_KBLOCK_SPECIALISED 0
+#endif
+
+#ifndef NLSH_TILED_KB
+#define NLSH_TILED_KB 4
+#endif
+
+#ifndef NLSH_ROW_PREFETCH
+#define NLSH_ROW_PREFETCH 0
+#endif
+
 #ifndef NLSH_ABLATE
 #define NLSH_ABLATE 0  // diagnostic timing builds only: 1 no distance math, 2 no global loads, 3 no top-k, 4 no scalar loads
 #endif
@@ -53,12 +81,27 @@ struct BArgs {
     int4 *task;
     uint64_t *partial;
     long long max_tasks;
+    const int32_t *border;     // [nb] schedule order of the buckets (largest first) or nullptr = CSR order
+    int32_t *btot;             // [2 * blocks of bscan] per-block (pairs, tasks) totals
     unsigned long long *tauq;  // [Q] running upper bound of each query's k-th best key (atomicMin), KEY_NONE-initialised
     const float *qpad;  // tiled variant: queries padded to d4p*4 floats (L2: pad = -eps; cosine: pre-normalised, pad = 0)
     float *qpad_w;      // same buffer, writable (bprep); qpad aliases `queries` when no padding/normalisation is needed
     long long qpad_stride;
     int d4p;
 };
+
+// one launch instead of five hipMemsetAsync nodes (4.8 us each on this runtime): shared bounds to KEY_NONE,
+// candidate counts, bucket probe counts, cursors and the status words to zero
+__global__ __launch_bounds__(256) void binit_kernel(BArgs a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < a.Q) {
+        a.tauq[i] = KEY_NONE;
+        a.out_ncand[i] = 0;
+    }
+    if (i < a.nb) a.bcount[i] = 0;
+    if (i < 4) a.counters[i] = 0;
+    if (i < 2) a.status[i] = 0;
+}
 
 __global__ __launch_bounds__(256) void bplan_kernel(BArgs a) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -103,28 +146,62 @@ __device__ __forceinline__ int block_excl_scan(int v, int *wsum, int *total) {
     return woff + incl - v;
 }
 
+// Tasks are numbered in SCHEDULE order: bucket `border[i]` (buckets by descending size, fixed at index build)
+// is handled by thread i, so the heavy (segment x query-group) tasks of the big buckets get the low ids and are
+// dispatched first, the single small tasks of the small buckets last: the kernel no longer ends on a tail of
+// 40-us tasks started in its last microseconds (measured: machine full until 370 us, drained until 440 us).
+// Numbering is deterministic: bcount_kernel leaves per-block totals, bscan_kernel sums the totals of the
+// blocks before it (no atomics, no dependence on block timing).
+__device__ __forceinline__ void bucket_task_counts(const BArgs &a, int i, int &b, int &m, int &s, int &ns, int &ng) {
+    b = a.border ? a.border[i] : i;
+    m = a.bcount[b];
+    s = a.offsets[b + 1] - a.offsets[b];
+    ns = (s + a.seg - 1) / a.seg;
+    ng = (m + a.QB - 1) / a.QB;
+}
+
+__global__ __launch_bounds__(256) void bcount_kernel(BArgs a) {
+    __shared__ int wsum[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int b, m = 0, s, ns = 0, ng = 0;
+    if (i < a.nb) bucket_task_counts(a, i, b, m, s, ns, ng);
+    int tot_m, tot_t;
+    block_excl_scan(m, wsum, &tot_m);
+    block_excl_scan(ng * ns, wsum, &tot_t);
+    if (threadIdx.x == 0) {
+        a.btot[2 * blockIdx.x] = tot_m;
+        a.btot[2 * blockIdx.x + 1] = tot_t;
+    }
+}
+
 __global__ __launch_bounds__(256) void bscan_kernel(BArgs a) {
     __shared__ int wsum[4];
     __shared__ int base_m, base_t;
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    int m = 0, s = 0, ns = 0, ng = 0, nt = 0;
-    if (b < a.nb) {
-        m = a.bcount[b];
-        s = a.offsets[b + 1] - a.offsets[b];
-        ns = (s + a.seg - 1) / a.seg;
-        ng = (m + a.QB - 1) / a.QB;
-        nt = ng * ns;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int b = 0, m = 0, s = 0, ns = 0, ng = 0;
+    if (i < a.nb) {
+        bucket_task_counts(a, i, b, m, s, ns, ng);
         a.bgroups[b] = ng;
     }
-    int tot_m, tot_t;
+    const int nt = ng * ns;
+    // totals of the blocks before this one (and, in the last block, of all blocks -> status[0])
+    int pm = 0, pt = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) {
+        pm += a.btot[2 * j];
+        pt += a.btot[2 * j + 1];
+    }
+    int tot_m, tot_t, dummy;
     const int ex_m = block_excl_scan(m, wsum, &tot_m);
     const int ex_t = block_excl_scan(nt, wsum, &tot_t);
+    block_excl_scan(pm, wsum, &dummy);
+    if (threadIdx.x == 0) base_m = dummy;
+    block_excl_scan(pt, wsum, &dummy);
     if (threadIdx.x == 0) {
-        base_m = tot_m ? atomicAdd(&a.counters[0], tot_m) : 0;
-        base_t = tot_t ? atomicAdd(&a.status[0], tot_t) : 0;
+        base_t = dummy;
+        if (blockIdx.x == gridDim.x - 1) a.status[0] = dummy + tot_t;  // tasks needed (may exceed max_tasks: the caller retries)
     }
     __syncthreads();
-    if (b < a.nb) {
+    if (i < a.nb) {
         const int po = base_m + ex_m, to = base_t + ex_t;
         a.pairoff[b] = po;
         a.taskoff[b] = to;
@@ -133,7 +210,7 @@ __global__ __launch_bounds__(256) void bscan_kernel(BArgs a) {
             const long long tt = (long long)to + t;
             if (tt >= a.max_tasks) break;
             // segment-major: the query groups of one row segment get consecutive task ids, so they run
-            // at about the same time (and, with the XCD-chunked block map of bscan3, on one XCD's L2)
+            // at about the same time (and, with the chunked XCD map of bscan3, on one XCD's L2)
             const int si = t / ng, gi = t - si * ng;
             a.task[tt] = make_int4(po + gi * a.QB, min(a.QB, m - gi * a.QB), row0 + si * a.seg, min(a.seg, s - si * a.seg));
         }
@@ -301,8 +378,23 @@ __device__ __forceinline__ void load_qchunk(QChunk<QW> &qc, const const_f32p (&q
         }
 }
 
+template <int METRIC, int QW, int NQ>
+__device__ __forceinline__ void apply_qchunk(const QChunk<NQ> &qc, const float4 rv, float (&acc)[QW]) {
+#pragma unroll
+    for (int jq = 0; jq < NQ; ++jq) {
+        const float q0 = qc.v[jq][0], q1 = qc.v[jq][1], q2 = qc.v[jq][2], q3 = qc.v[jq][3];
+        if (METRIC == NLSH_METRIC_L2_EPS) {
+            // F.pairwise_distance: || (x1 - x2) + eps ||, summed in k order (nlsh/data.py:201)
+            const float t0 = (q0 - rv.x) + 1e-6f, t1 = (q1 - rv.y) + 1e-6f, t2 = (q2 - rv.z) + 1e-6f, t3 = (q3 - rv.w) + 1e-6f;
+            acc[jq] = fmaf(t3, t3, fmaf(t2, t2, fmaf(t1, t1, fmaf(t0, t0, acc[jq]))));
+        } else {
+            acc[jq] = fmaf(q3, rv.w, fmaf(q2, rv.z, fmaf(q1, rv.y, fmaf(q0, rv.x, acc[jq]))));
+        }
+    }
+}
+
 template <int METRIC, int QW, bool FULL>
-__device__ __forceinline__ void apply_qchunk(const QChunk<QW> &qc, const float4 rv, int nqw, float (&acc)[QW]) {
+__device__ __forceinline__ void apply_qchunk_guarded(const QChunk<QW> &qc, const float4 rv, int nqw, float (&acc)[QW]) {
 #pragma unroll
     for (int jq = 0; jq < QW; ++jq) {
         if (FULL || jq < nqw) {
@@ -318,6 +410,126 @@ __device__ __forceinline__ void apply_qchunk(const QChunk<QW> &qc, const float4 
     }
 }
 
+// s_waitcnt lgkmcnt(0) only (vmcnt / expcnt untouched): gfx9 encoding vmcnt[3:0]|expcnt[6:4]|lgkmcnt[11:8]|vmcnt_hi[15:14]
+#define NLSH_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
+
+// One k-block (<= KB 16-byte chunks) of NQ queries x NTL row tiles, BRANCH-FREE (the counts are template
+// parameters, bscan3 dispatches on them once per k-block).  Both operand streams are double buffered by hand:
+// the wait for chunk c's operands (LDS rows + scalar-loaded queries share lgkmcnt, and SMEM returns out of
+// order, so it is always lgkmcnt(0)) is placed BEFORE chunk c+1's loads are issued; those then fly under
+// chunk c's NQ*NTL*12 VALU instructions.  (The guarded generic body it replaces issued each ds_read_b128
+// right before its use, behind a scalar branch: the LDS round trip was exposed once per tile and chunk.)
+template <int METRIC, int QW, int TPS, int RS, int NQ, int NTL>
+__device__ __forceinline__ void kblock_compute(const float4 *col, const const_f32p (&qk)[QW], int nchunk, float (&acc)[TPS][QW]) {
+    const_f32p qn[NQ];
+#pragma unroll
+    for (int jq = 0; jq < NQ; ++jq) qn[jq] = qk[jq];
+    QChunk<NQ> qa, qb;
+    float4 ra[NTL], rb[NTL];
+    load_qchunk<NQ, true>(qa, qn, NQ, 0);
+#pragma unroll
+    for (int tl = 0; tl < NTL; ++tl) ra[tl] = col[tl * 64 * RS];
+    for (int c = 0; c < nchunk; c += 2) {
+        const int c1 = min(c + 1, nchunk - 1);
+        NLSH_WAIT_LGKM0();
+        load_qchunk<NQ, true>(qb, qn, NQ, c1);
+#pragma unroll
+        for (int tl = 0; tl < NTL; ++tl) rb[tl] = col[tl * 64 * RS + c1];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tl = 0; tl < NTL; ++tl) {
+            apply_qchunk<METRIC, QW, NQ>(qa, ra[tl], acc[tl]);
+            __builtin_amdgcn_sched_barrier(0);  // one tile's temporaries at a time (register pressure -> 4 waves/SIMD)
+        }
+        if (c + 1 >= nchunk) break;
+        const int c2 = min(c + 2, nchunk - 1);
+        NLSH_WAIT_LGKM0();
+        load_qchunk<NQ, true>(qa, qn, NQ, c2);
+#pragma unroll
+        for (int tl = 0; tl < NTL; ++tl) ra[tl] = col[tl * 64 * RS + c2];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tl = 0; tl < NTL; ++tl) {
+            apply_qchunk<METRIC, QW, NQ>(qb, rb[tl], acc[tl]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// The full wave (QW queries x TPS tiles) without guards and without hand-placed buffering: the query chunks go
+// through two scalar register sets as in the generic loop, the TPS row chunks are read at the top of each step.
+template <int METRIC, int QW, int TPS, int RS>
+__device__ __forceinline__ void kblock_full(const float4 *col, const const_f32p (&qk)[QW], int nchunk, float (&acc)[TPS][QW]) {
+    QChunk<QW> qa, qb;
+    load_qchunk<QW, true>(qa, qk, QW, 0);
+    for (int c = 0; c < nchunk; c += 2) {
+        const bool has1 = c + 1 < nchunk;
+        load_qchunk<QW, true>(qb, qk, QW, has1 ? c + 1 : c);
+#pragma unroll
+        for (int tl = 0; tl < TPS; ++tl) apply_qchunk<METRIC, QW, QW>(qa, col[tl * 64 * RS + c], acc[tl]);
+        if (!has1) break;
+        load_qchunk<QW, true>(qa, qk, QW, c + 2 < nchunk ? c + 2 : c);
+#pragma unroll
+        for (int tl = 0; tl < TPS; ++tl) apply_qchunk<METRIC, QW, QW>(qb, col[tl * 64 * RS + c + 1], acc[tl]);
+    }
+}
+
+// The full wave again, branch-free but in the generic loop's strict (tile, query) order: a scheduling barrier after
+// every query's 12 instructions keeps the live temporaries at 4 registers (left alone, the scheduler interleaves
+// the 16 blocks for ILP and the kernel needs ~120 VGPRs: 4 waves/SIMD instead of 7).
+template <int METRIC, int QW, int TPS, int RS>
+__device__ __forceinline__ void kblock_full_ordered(const float4 *col, const const_f32p (&qk)[QW], int nchunk, float (&acc)[TPS][QW]) {
+    QChunk<QW> qa, qb;
+    load_qchunk<QW, true>(qa, qk, QW, 0);
+    auto step = [&](const QChunk<QW> &qc, int c) {
+#pragma unroll
+        for (int tl = 0; tl < TPS; ++tl) {
+            const float4 rv = col[tl * 64 * RS + c];
+#pragma unroll
+            for (int jq = 0; jq < QW; ++jq) {
+                const float q0 = qc.v[jq][0], q1 = qc.v[jq][1], q2 = qc.v[jq][2], q3 = qc.v[jq][3];
+                if (METRIC == NLSH_METRIC_L2_EPS) {
+                    const float t0 = (q0 - rv.x) + 1e-6f, t1 = (q1 - rv.y) + 1e-6f, t2 = (q2 - rv.z) + 1e-6f, t3 = (q3 - rv.w) + 1e-6f;
+                    acc[tl][jq] = fmaf(t3, t3, fmaf(t2, t2, fmaf(t1, t1, fmaf(t0, t0, acc[tl][jq]))));
+                } else {
+                    acc[tl][jq] = fmaf(q3, rv.w, fmaf(q2, rv.z, fmaf(q1, rv.y, fmaf(q0, rv.x, acc[tl][jq]))));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    for (int c = 0; c < nchunk; c += 2) {
+        const bool has1 = c + 1 < nchunk;
+        load_qchunk<QW, true>(qb, qk, QW, has1 ? c + 1 : c);
+        __builtin_amdgcn_sched_barrier(0);
+        step(qa, c);
+        if (!has1) break;
+        load_qchunk<QW, true>(qa, qk, QW, c + 2 < nchunk ? c + 2 : c);
+        __builtin_amdgcn_sched_barrier(0);
+        step(qb, c + 1);
+    }
+}
+
+template <int METRIC, int QW, int TPS, int RS, int NTL>
+__device__ __forceinline__ void kblock_by_queries(int nqw, const float4 *col, const const_f32p (&qk)[QW], int nchunk, float (&acc)[TPS][QW]) {
+    static_assert(QW == 4, "dispatch below enumerates 1..4 queries per wave");
+    switch (nqw) {
+    case 1: kblock_compute<METRIC, QW, TPS, RS, 1, NTL>(col, qk, nchunk, acc); break;
+    case 2: kblock_compute<METRIC, QW, TPS, RS, 2, NTL>(col, qk, nchunk, acc); break;
+    case 3: kblock_compute<METRIC, QW, TPS, RS, 3, NTL>(col, qk, nchunk, acc); break;
+    default: kblock_compute<METRIC, QW, TPS, RS, 4, NTL>(col, qk, nchunk, acc); break;
+    }
+}
+
+template <int METRIC, int QW, int TPS, int RS>
+__device__ __forceinline__ void kblock_dispatch(int nqw, int ntile, const float4 *col, const const_f32p (&qk)[QW], int nchunk, float (&acc)[TPS][QW]) {
+    static_assert(TPS == 4 || TPS == 2 || TPS == 1, "dispatch below enumerates up to 4 tiles");
+    if (TPS >= 4 && ntile >= 4) kblock_by_queries<METRIC, QW, TPS, RS, (TPS >= 4 ? 4 : TPS)>(nqw, col, qk, nchunk, acc);
+    else if (TPS >= 4 && ntile == 3) kblock_by_queries<METRIC, QW, TPS, RS, (TPS >= 4 ? 3 : TPS)>(nqw, col, qk, nchunk, acc);
+    else if (TPS >= 2 && ntile >= 2) kblock_by_queries<METRIC, QW, TPS, RS, (TPS >= 2 ? 2 : TPS)>(nqw, col, qk, nchunk, acc);
+    else kblock_by_queries<METRIC, QW, TPS, RS, 1>(nqw, col, qk, nchunk, acc);
+}
+
 // QW queries per wave, NW waves per workgroup (QW*NW queries per task), TPS 64-row tiles per task.
 // k-blocks of KB chunks are the OUTER loop: one stage holds the KB-chunk slice of ALL 64*TPS rows of
 // the segment in LDS, so every scalar-loaded query chunk is applied to TPS row tiles (TPS x fewer
@@ -327,7 +539,7 @@ __device__ __forceinline__ void apply_qchunk(const QChunk<QW> &qc, const float4 
 template <int METRIC, int QW, int NW, int TPS>
 __global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
     constexpr int NT = 64 * NW;              // threads per workgroup
-    constexpr int KB = 8;                    // 16-byte chunks per k-block (32 floats)
+    constexpr int KB = NLSH_TILED_KB;        // 16-byte chunks per k-block
     constexpr int RS = KB + 1;               // odd LDS row stride (16-byte slots) -> conflict-free column reads
     constexpr int ROWS = 64 * TPS;
     constexpr int SPT = ROWS * KB / NT;      // staged 16-byte words per thread and stage
@@ -339,12 +551,17 @@ __global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
         if (blockIdx.x == 0 && threadIdx.x == 0) a.status[1] = 1;  // incomplete: caller must retry
         ntasks = a.max_tasks;
     }
-    // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2): give each XCD a
-    // CONTIGUOUS range of task ids, so the query groups of one row segment (consecutive ids) re-read
-    // its rows from that XCD's L2 instead of HBM.  Placement only changes speed, never results.
-    const long long per_xcd = (ntasks + 7) >> 3;
-    const long long t = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if ((long long)(blockIdx.x >> 3) >= per_xcd || t >= ntasks) return;
+    // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Task ids are dealt to the XCDs
+    // in CHUNKS of 16 consecutive ids: the query groups of one row segment (consecutive ids) mostly land on one
+    // XCD and re-read its rows from that L2 instead of HBM, while every XCD still walks the size-ordered task
+    // list front to back (a contiguous 1/8 range per XCD would hand all the heavy tasks to XCD 0).
+    // Placement only changes speed, never results.
+    constexpr int XC = 16;
+    const long long j = blockIdx.x >> 3;
+    const long long t = ((j / XC) * 8 + (blockIdx.x & 7)) * XC + (j % XC);
+    if (t >= ntasks) return;
+    [[maybe_unused]] const unsigned long long ts0 = SCAN_NOW();
+    [[maybe_unused]] unsigned long long ts_stage = 0, ts_comp = 0;
     const int4 desc = a.task[t];
     const int pair0 = __builtin_amdgcn_readfirstlane(desc.x);
     const int nq = __builtin_amdgcn_readfirstlane(desc.y);
@@ -386,34 +603,95 @@ __global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
         for (int jq = 0; jq < QW; ++jq) acc[tl][jq] = 0.0f;
 
     stage_load(0);
+    [[maybe_unused]] const unsigned long long ts1 = SCAN_NOW();
     for (int kb = 0; kb < nkb; ++kb) {
+        const unsigned long long ta = SCAN_NOW();
         __syncthreads();  // everyone has finished reading the previous k-block
 #pragma unroll
         for (int i = 0; i < SPT; ++i) tile[(sr + RPP * i) * RS + sc] = stg[i];
         __syncthreads();
         if (kb + 1 < nkb) stage_load(kb + 1);  // in flight while this k-block is computed
+        const unsigned long long tb = SCAN_NOW();
+        ts_stage += tb - ta;
         if (NLSH_ABLATE != 1 && nqw > 0) {
             const int nchunk = min(KB, d4 - kb * KB);
             const_f32p qk[QW];
 #pragma unroll
             for (int jq = 0; jq < QW; ++jq) qk[jq] = qs[jq] + kb * KB * 4;
+#if NLSH_KBLOCK_SPECIALISED == 2
+            kblock_dispatch<METRIC, QW, TPS, RS>(nqw, ntile, tile + lane * RS, qk, nchunk, acc);
+#else
+            if (NLSH_KBLOCK_SPECIALISED == 1 && nqw == QW && ntile == TPS) {
+                // the full (QW queries x TPS tiles) wave: 65 % of the tile-query work of the headline run
+                kblock_compute<METRIC, QW, TPS, RS, QW, TPS>(tile + lane * RS, qk, nchunk, acc);
+            } else if (NLSH_KBLOCK_SPECIALISED == 3 && nqw == QW && ntile == TPS) {
+                kblock_full<METRIC, QW, TPS, RS>(tile + lane * RS, qk, nchunk, acc);
+            } else if (NLSH_KBLOCK_SPECIALISED == 4 && nqw == QW && ntile == TPS) {
+                kblock_full_ordered<METRIC, QW, TPS, RS>(tile + lane * RS, qk, nchunk, acc);
+            } else {
             const float4 *col = tile + lane * RS;
             QChunk<QW> qa, qb;
             load_qchunk<QW, false>(qa, qk, nqw, 0);
+#if NLSH_ROW_PREFETCH
+            // The row chunk of the NEXT (chunk, tile) step is read from LDS before the current step's math, so its
+            // round trip hides under the step's <= QW*12 VALU instructions (read right before its use it was
+            // exposed once per tile and chunk: ~128 LDS round trips per task and wave).
+            float4 rcur = col[0];
             for (int c = 0; c < nchunk; c += 2) {
                 const bool has1 = c + 1 < nchunk;
                 load_qchunk<QW, false>(qb, qk, nqw, has1 ? c + 1 : c);
 #pragma unroll
                 for (int tl = 0; tl < TPS; ++tl)
-                    if (tl < ntile) apply_qchunk<METRIC, QW, false>(qa, col[tl * 64 * RS + c], nqw, acc[tl]);
+                    if (tl < ntile) {
+                        const bool wrap = tl + 1 >= ntile;
+                        const float4 rnext = col[(wrap ? 0 : tl + 1) * 64 * RS + (wrap && has1 ? c + 1 : c)];
+                        __builtin_amdgcn_sched_barrier(0);
+                        apply_qchunk_guarded<METRIC, QW, false>(qa, rcur, nqw, acc[tl]);
+                        rcur = rnext;
+                    }
+                if (!has1) break;
+                const bool has2 = c + 2 < nchunk;
+                load_qchunk<QW, false>(qa, qk, nqw, has2 ? c + 2 : c);
+#pragma unroll
+                for (int tl = 0; tl < TPS; ++tl)
+                    if (tl < ntile) {
+                        const bool wrap = tl + 1 >= ntile;
+                        const float4 rnext = col[(wrap ? 0 : tl + 1) * 64 * RS + (wrap && has2 ? c + 2 : c + 1)];
+                        __builtin_amdgcn_sched_barrier(0);
+                        apply_qchunk_guarded<METRIC, QW, false>(qb, rcur, nqw, acc[tl]);
+                        rcur = rnext;
+                    }
+            }
+#else
+            for (int c = 0; c < nchunk; c += 2) {
+                const bool has1 = c + 1 < nchunk;
+                load_qchunk<QW, false>(qb, qk, nqw, has1 ? c + 1 : c);
+#pragma unroll
+                for (int tl = 0; tl < TPS; ++tl)
+                    if (tl < ntile) apply_qchunk_guarded<METRIC, QW, false>(qa, col[tl * 64 * RS + c], nqw, acc[tl]);
                 if (!has1) break;
                 load_qchunk<QW, false>(qa, qk, nqw, c + 2 < nchunk ? c + 2 : c);
 #pragma unroll
                 for (int tl = 0; tl < TPS; ++tl)
-                    if (tl < ntile) apply_qchunk<METRIC, QW, false>(qb, col[tl * 64 * RS + c + 1], nqw, acc[tl]);
+                    if (tl < ntile) apply_qchunk_guarded<METRIC, QW, false>(qb, col[tl * 64 * RS + c + 1], nqw, acc[tl]);
             }
+#endif
+            }
+#endif
         }
+#ifdef NLSH_SCAN_TRACE
+        {   // the accumulators must exist before the stamp: make the stamp depend on one of them
+            float sink = 0.f;
+#pragma unroll
+            for (int tl = 0; tl < TPS; ++tl)
+#pragma unroll
+                for (int jq = 0; jq < QW; ++jq) sink += acc[tl][jq];
+            asm volatile("" ::"v"(sink));
+            ts_comp += SCAN_NOW() - tb;
+        }
+#endif
     }
+    [[maybe_unused]] const unsigned long long ts2 = SCAN_NOW();
     if (nqw == 0) return;
     // lane = row of each tile -> one candidate per lane, tile and query
     // Lists of the same query in other tasks publish their k-th best key to tauq[q] (atomicMin): no
@@ -431,6 +709,10 @@ __global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
         mygid[tl] = valid[tl] ? a.gid[prow] : -1;
         myinv[tl] = (METRIC == NLSH_METRIC_COSINE && valid[tl]) ? a.inv_norm[prow] : 0.0f;
     }
+#ifdef NLSH_SCAN_TRACE
+    asm volatile("" ::"v"(mygid[0]));
+#endif
+    [[maybe_unused]] const unsigned long long ts3 = SCAN_NOW();
 #pragma unroll
     for (int jq = 0; jq < QW; ++jq) {
         if (jq < nqw) {
@@ -449,6 +731,14 @@ __global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
             } else if (lane < a.k) out[lane] = key[0];
         }
     }
+#ifdef NLSH_SCAN_TRACE
+    if (tid == 0 && t < NLSH_TRACE_SLOTS) {
+        const unsigned long long ts4 = SCAN_NOW();
+        float *o = g_scan_trace + t * 8;
+        o[0] = (float)(ts4 - ts0); o[1] = (float)(ts1 - ts0); o[2] = (float)ts_stage; o[3] = (float)ts_comp;
+        o[4] = (float)(ts0 & 0xFFFFFFull); o[5] = (float)(ts4 - ts3); o[6] = (float)nq; o[7] = (float)nrows;
+    }
+#endif
 }
 
 __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
@@ -498,7 +788,7 @@ constexpr int TILED_QB = NLSH_TILED_QB;  // queries per task of the tiled schedu
 constexpr int TILED_TPS = NLSH_TILED_TPS;  // 64-row tiles per task of the tiled schedule (segment = 64*TPS rows)
 
 struct BWs {
-    size_t pbkt, pairpos, inv_q, bcount, pairoff, taskoff, bgroups, counters, task, partial, qpad, tauq, total;
+    size_t pbkt, pairpos, inv_q, bcount, pairoff, taskoff, bgroups, counters, btot, task, partial, qpad, tauq, total;
 };
 static void blayout(long long Q, int P, int k, long long max_tasks, long long nb, int d, bool tiled, BWs *w) {
     size_t o = 0;
@@ -511,6 +801,7 @@ static void blayout(long long Q, int P, int k, long long max_tasks, long long nb
     w->taskoff = o;  o += ws_align(nb4);
     w->bgroups = o;  o += ws_align(nb4);
     w->counters = o; o += ws_align(16);
+    w->btot = o;     o += ws_align((size_t)((nb + 255) / 256 + 1) * 8);
     w->task = o;     o += ws_align((size_t)max_tasks * sizeof(int4));
     w->partial = o;  o += ws_align((size_t)max_tasks * (tiled ? TILED_QB : 8) * k * 8);
     w->qpad = o;     o += tiled ? ws_align((size_t)Q * ((d + 3) / 4) * 16) : 0;
@@ -551,25 +842,29 @@ int bucket_scan_run(const BucketScanCall &c) {
     char *base = (char *)c.workspace;
     a.pbkt = (int32_t *)(base + w.pbkt); a.pairpos = (int32_t *)(base + w.pairpos); a.inv_q = (int32_t *)(base + w.inv_q);
     a.bcount = (int32_t *)(base + w.bcount); a.pairoff = (int32_t *)(base + w.pairoff); a.taskoff = (int32_t *)(base + w.taskoff); a.bgroups = (int32_t *)(base + w.bgroups);
-    a.counters = (int32_t *)(base + w.counters); a.task = (int4 *)(base + w.task); a.partial = (uint64_t *)(base + w.partial);
+    a.counters = (int32_t *)(base + w.counters); a.btot = (int32_t *)(base + w.btot); a.border = c.bucket_order; a.task = (int4 *)(base + w.task); a.partial = (uint64_t *)(base + w.partial);
     a.max_tasks = c.max_tasks;
     a.tauq = (unsigned long long *)(base + w.tauq);
 
     hipStream_t s = c.stream;
-    NLSH_CHECK_HIP(hipMemsetAsync(a.tauq, 0xFF, (size_t)c.Q * 8, s));  // KEY_NONE
-    NLSH_CHECK_HIP(hipMemsetAsync(c.status, 0, 2 * sizeof(int32_t), s));
-    NLSH_CHECK_HIP(hipMemsetAsync(a.counters, 0, 16, s));
-    NLSH_CHECK_HIP(hipMemsetAsync(a.bcount, 0, (size_t)(c.nb > 0 ? c.nb : 1) * 4, s));
-    NLSH_CHECK_HIP(hipMemsetAsync(c.out_ncand, 0, (size_t)c.Q * 4, s));
+    {
+        long long n_init = c.Q > c.nb ? c.Q : c.nb;
+        if (n_init < 4) n_init = 4;
+        hipLaunchKernelGGL(binit_kernel, dim3((unsigned)((n_init + 255) / 256)), dim3(256), 0, s, a);
+    }
     const unsigned gp = (unsigned)((c.Q * c.P + 255) / 256);
     hipLaunchKernelGGL(bplan_kernel, dim3(gp), dim3(256), 0, s, a);
-    if (c.nb > 0) hipLaunchKernelGGL(bscan_kernel, dim3((unsigned)((c.nb + 255) / 256)), dim3(256), 0, s, a);
+    if (c.nb > 0) {
+        const unsigned gb = (unsigned)((c.nb + 255) / 256);
+        hipLaunchKernelGGL(bcount_kernel, dim3(gb), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(bscan_kernel, dim3(gb), dim3(256), 0, s, a);
+    }
     hipLaunchKernelGGL(bscatter_kernel, dim3(gp), dim3(256), 0, s, a);
     if (prep) hipLaunchKernelGGL(bprep_kernel, dim3((unsigned)c.Q), dim3(64), 0, s, a, c.metric);
     if (c.max_tasks > 0) {
         if (c.ev_begin) NLSH_CHECK_HIP(hipEventRecord((hipEvent_t)c.ev_begin, s));
         if (c.tiled) {
-            const unsigned grid = (unsigned)(c.max_tasks + 8);  // one workgroup per task (+8: XCD-chunked id map rounds up)
+            const unsigned grid = (unsigned)((c.max_tasks + 127) / 128 * 128);  // one workgroup per task (the chunked XCD map works on 8 x 16 ids)
             // QW = 4 queries per wave (SGPR budget: two chunks x QW x 4 scalar values in flight), NW = 4 waves
             if (c.metric == NLSH_METRIC_L2_EPS) hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_L2_EPS, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
             else hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_COSINE, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);

@@ -213,6 +213,7 @@ struct BucketScanCall {
     const float *inv_norm; const float *queries; long long q_stride; long long Q; const int32_t *qkeys; const int32_t *nkeys;
     int P, k, metric, seg; float *out_dist; int32_t *out_idx; uint64_t *out_keys; int32_t *out_ncand; int32_t *status;
     void *workspace; size_t workspace_bytes; long long max_tasks; void *ev_begin; void *ev_end; hipStream_t stream; int tiled;
+    const int32_t *bucket_order;  // nlsh_bucket_order output or nullptr
 };
 size_t bucket_scan_workspace(long long Q, int P, int k, long long max_tasks, long long n_buckets, int d);
 int bucket_scan_run(const BucketScanCall &c);

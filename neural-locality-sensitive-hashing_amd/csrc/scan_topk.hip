@@ -272,8 +272,8 @@ extern "C" size_t nlsh_scan_workspace(int64_t Q, int P, int k, int64_t max_tasks
 }
 
 extern "C" int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, int d, const int32_t *gid,
-                              const int32_t *uniq_keys, const int32_t *offsets, int32_t n_buckets, const float *inv_norm,
-                              const float *queries, int64_t q_stride, int64_t Q, const int32_t *qkeys, const int32_t *nkeys,
+                              const int32_t *uniq_keys, const int32_t *offsets, const int32_t *bucket_order, int32_t n_buckets,
+                              const float *inv_norm, const float *queries, int64_t q_stride, int64_t Q, const int32_t *qkeys, const int32_t *nkeys,
                               int P, int k, int metric, int algo, int seg_rows, float *out_dist, int32_t *out_idx,
                               uint64_t *out_keys, int32_t *out_ncand, int32_t *status, void *workspace, size_t workspace_bytes,
                               int64_t max_tasks, void *ev_scan_begin, void *ev_scan_end, nlsh_stream_t stream) {
@@ -299,7 +299,7 @@ extern "C" int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, in
     if (algo != NLSH_SCAN_QUERY_MAJOR) {
         BucketScanCall c = {corpus_sorted, row_stride, d, gid, uniq_keys, offsets, n_buckets, inv_norm, queries, q_stride, Q,
                             qkeys, nkeys, P, k, metric, seg_rows, out_dist, out_idx, out_keys, out_ncand, status, workspace,
-                            workspace_bytes, max_tasks, ev_scan_begin, ev_scan_end, s, algo == NLSH_SCAN_BUCKET_TILED};
+                            workspace_bytes, max_tasks, ev_scan_begin, ev_scan_end, s, algo == NLSH_SCAN_BUCKET_TILED, bucket_order};
         return bucket_scan_run(c);
     }
 

@@ -22,7 +22,7 @@ MAX_LAYERS, MAX_HASH_BITS, MAX_PROBES, MAX_K, MAX_DIM, MAX_WIDTH = 8, 32, 64, 64
 SYMBOLS = (
     "nlsh_abi_version", "nlsh_last_error",
     "nlsh_encoder_packed_floats", "nlsh_encoder_pack", "nlsh_encode_hash", "nlsh_pack_codes",
-    "nlsh_build_csr_workspace", "nlsh_build_csr", "nlsh_gather_rows",
+    "nlsh_build_csr_workspace", "nlsh_build_csr", "nlsh_bucket_order_workspace", "nlsh_bucket_order", "nlsh_gather_rows",
     "nlsh_scan_workspace", "nlsh_scan_topk", "nlsh_merge_topk",
 )
 
@@ -68,12 +68,16 @@ def lib():
     L.nlsh_build_csr_workspace.argtypes = [i64]
     L.nlsh_build_csr.restype = i32
     L.nlsh_build_csr.argtypes = [vp, i64, vp, vp, vp, vp, vp, sz, vp]
+    L.nlsh_bucket_order_workspace.restype = sz
+    L.nlsh_bucket_order_workspace.argtypes = [i64]
+    L.nlsh_bucket_order.restype = i32
+    L.nlsh_bucket_order.argtypes = [vp, i64, vp, vp, sz, vp]
     L.nlsh_gather_rows.restype = i32
     L.nlsh_gather_rows.argtypes = [vp, i64, i32, vp, i64, vp, i64, vp, vp, ctypes.c_int32, vp]
     L.nlsh_scan_workspace.restype = sz
     L.nlsh_scan_workspace.argtypes = [i64, i32, i32, i64, i64, i32]
     L.nlsh_scan_topk.restype = i32
-    L.nlsh_scan_topk.argtypes = [vp, i64, i32, vp, vp, vp, ctypes.c_int32, vp, vp, i64, i64, vp, vp, i32, i32, i32, i32, i32,
+    L.nlsh_scan_topk.argtypes = [vp, i64, i32, vp, vp, vp, vp, ctypes.c_int32, vp, vp, i64, i64, vp, vp, i32, i32, i32, i32, i32,
                                  vp, vp, vp, vp, vp, vp, sz, i64, vp, vp, vp]
     L.nlsh_merge_topk.restype = i32
     L.nlsh_merge_topk.argtypes = [vp, i64, i32, i64, i32, vp, vp, vp, vp, vp]

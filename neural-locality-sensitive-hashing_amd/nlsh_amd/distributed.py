@@ -1,16 +1,25 @@
 """Corpus sharding across the GPUs of one node; the reference has no
 distributed code at all, this is the MI355X-native addition BASELINE.json's north_star asks for.
 
-One process per GPU.  Rank r owns a contiguous row range of the corpus (so every bucket is split
-~evenly over ranks and each rank scans C_q/G candidates per query), builds its own CSR with GLOBAL
-row ids (`id_base`), and answers the full (replicated) query batch over its shard.  The only
-exchange step is ONE all-gather (RCCL over xGMI when the backend is "nccl") of the per-rank
-`[Q, k]` 64-bit (distance,id) keys + `[Q]` candidate counts, followed by the same
+One process per GPU.  Two partitions of the corpus, same query-time protocol:
+
+* shard="buckets" (default; north_star: "shard the corpus buckets across the 8 GPUs"): every bucket lives
+  WHOLE on one rank.  Build: each rank encodes its contiguous row range, the int32 keys are all-gathered
+  (4 B/row), every rank derives the same bucket -> owner table (buckets ordered by size, dealt in snake
+  order, so row counts and the size-squared scan work are both balanced), and ONE all-to-all moves each row
+  (+ its global id) to the owner of its bucket.  A rank then scans 1/G of the (bucket, query-group) tasks at
+  full bucket size, so the bucket-major scan keeps its row reuse as G grows.
+* shard="rows": rank r keeps its contiguous row range; every bucket is split ~evenly over the ranks.  No
+  build-time exchange, perfectly balanced under any skew, but each rank still runs every task on 1/G of the
+  rows (measured: the tiled scan only drops 0.42 -> 0.17 ms from G=1 to G=8).
+
+Query time (both): every rank hashes the full, replicated query batch (multi-probe keys are identical on
+every rank: the Philox stream is keyed by (seed, global query row, probe) and hard bits are deterministic),
+scans its own shard, and the only exchange step is ONE all-gather (RCCL over xGMI when the backend is
+"nccl") of the per-rank `[Q, k]` 64-bit (distance,id) keys + `[Q]` candidate counts, followed by the same
 (distance, id) merge the single-GPU path uses -> results identical to one GPU.
-Multi-probe keys are identical on every rank because the Philox stream is keyed by
-(seed, global query row, probe) and the hard bits are deterministic.
 """
-from typing import Callable, Tuple
+from typing import Callable, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -57,17 +66,123 @@ def gather_and_merge(local_keys: torch.Tensor, local_ncand: torch.Tensor, k: int
     return merge_fn(packed_all.view(world, Q, k + 1), k)
 
 
-class ShardedIndexer:
-    """`Indexer` over this rank's corpus shard + the all-gather/merge exchange step."""
+# ----------------------------------------------------------------------------- bucket partition
+def assign_buckets(counts: torch.Tensor, world: int) -> torch.Tensor:
+    """Owner rank of every bucket, given the bucket sizes in ascending-key order (int64 [nb]).
 
-    def __init__(self, hashing, local_corpus_gpu, distance_func, id_base: int, group=None, **kw):
+    Buckets are ordered by (size descending, key ascending) and dealt in snake order 0..G-1,G-1..0: every
+    rank gets one bucket of each size class per round, which balances rows (HBM) and sum of size^2 (the scan
+    work: a bucket is probed by a number of queries roughly proportional to its size).  Deterministic, so
+    every rank computes the same table without communication."""
+    nb = counts.shape[0]
+    order = torch.argsort(-counts.long(), stable=True)            # ties keep ascending-key order
+    pos = torch.arange(nb, device=counts.device)
+    rnd, r = pos // world, pos % world
+    owner_sorted = torch.where(rnd % 2 == 0, r, world - 1 - r)
+    owner = torch.empty((nb,), dtype=torch.int64, device=counts.device)
+    owner[order] = owner_sorted
+    return owner
+
+
+def corpus_statistics(counts: torch.Tensor) -> Tuple[float, float]:
+    """(size-biased mean bucket size, rows) of the whole corpus: what `Indexer.choose_algo` decides on."""
+    c = counts.double()
+    n = float(c.sum().item())
+    return (float((c * c).sum().item() / n) if n else 0.0), n
+
+
+def plan_bucket_shards(keys_all: torch.Tensor, world: int):
+    """All corpus keys (int32 [N]) -> (owner rank of every ROW int64 [N], (size-biased bucket, N))."""
+    uniq, inverse, counts = torch.unique(keys_all, return_inverse=True, return_counts=True)
+    return assign_buckets(counts, world)[inverse], corpus_statistics(counts)
+
+
+def _staged(t: torch.Tensor, group) -> bool:
+    # gloo rehearsals on device tensors go through the host; RCCL ("nccl") works on device memory directly
+    return t.device.type == "cuda" and dist.get_backend(group) == "gloo"
+
+
+def _all_gather_rows(t: torch.Tensor, group) -> torch.Tensor:
+    """All-gather of per-rank [n_r, ...] tensors with different n_r -> [sum n_r, ...] in rank order."""
+    world = dist.get_world_size(group)
+    dev = t.device
+    work = t.cpu() if _staged(t, group) else t
+    n = torch.tensor([work.shape[0]], dtype=torch.int64, device=work.device)
+    sizes = torch.empty((world,), dtype=torch.int64, device=work.device)
+    dist.all_gather_into_tensor(sizes, n, group=group)
+    sizes = sizes.cpu().tolist()
+    n_max = max(sizes)
+    padded = torch.zeros((n_max,) + tuple(work.shape[1:]), dtype=work.dtype, device=work.device)
+    padded[:work.shape[0]] = work
+    out = torch.empty((world * n_max,) + tuple(work.shape[1:]), dtype=work.dtype, device=work.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    out = torch.cat([out[r * n_max:r * n_max + sizes[r]] for r in range(world)])
+    return out.to(dev)
+
+
+def _all_to_all_rows(send: torch.Tensor, send_counts, recv_counts, group) -> torch.Tensor:
+    dev = send.device
+    work = send.cpu() if _staged(send, group) else send.contiguous()
+    out = torch.empty((int(sum(recv_counts)),) + tuple(work.shape[1:]), dtype=work.dtype, device=work.device)
+    dist.all_to_all_single(out, work, list(recv_counts), list(send_counts), group=group)
+    return out.to(dev)
+
+
+def exchange_rows_by_bucket(local_rows: torch.Tensor, local_keys: torch.Tensor, id_base: int, group=None):
+    """Build-time exchange of the bucket partition.  In: this rank's contiguous row range `[n_r, d]`, its
+    bucket keys (int32 [n_r]) and the global id of its first row.  Out: (rows this rank OWNS [m_r, d], their
+    global ids int32 [m_r] ascending within a bucket, (size-biased bucket, N) of the whole corpus).
+    Collectives: one all-gather of the keys, one of the [G] send counts, two all-to-alls (rows, ids)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    keys_all = _all_gather_rows(local_keys.view(-1), group)
+    lo = _all_gather_rows(torch.tensor([local_rows.shape[0]], dtype=torch.int64, device=local_keys.device), group)
+    start = int(lo[:rank].sum().item())
+    owner_all, stats = plan_bucket_shards(keys_all, world)
+    dest = owner_all[start:start + local_rows.shape[0]]
+    order = torch.argsort(dest, stable=True)                       # keeps ascending row order per destination
+    send_counts = torch.bincount(dest, minlength=world)
+    counts_all = _all_gather_rows(send_counts.view(1, world), group)      # [G, G]: row r = what rank r sends
+    recv_counts = counts_all[:, rank].cpu().tolist()
+    send_counts = send_counts.cpu().tolist()
+    rows = _all_to_all_rows(local_rows[order], send_counts, recv_counts, group)
+    ids = _all_to_all_rows((order + id_base).to(torch.int32), send_counts, recv_counts, group)
+    return rows, ids, stats
+
+
+def global_statistics(local_keys: torch.Tensor, group=None) -> Tuple[float, float]:
+    """Whole-corpus schedule statistics for the row partition (one all-gather of the keys)."""
+    keys_all = _all_gather_rows(local_keys.view(-1), group)
+    return corpus_statistics(torch.unique(keys_all, return_counts=True)[1])
+
+
+class ShardedIndexer:
+    """`Indexer` over this rank's part of the corpus + the all-gather/merge exchange step.
+
+    `local_corpus_gpu` is this rank's contiguous row range of the corpus and `id_base` the global id of its
+    first row.  shard="buckets" re-partitions it at build time (see module docstring); shard="rows" keeps it."""
+
+    def __init__(self, hashing, local_corpus_gpu, distance_func, id_base: int, group=None, shard: str = "buckets", **kw):
         from .indexer import Indexer
+        if shard not in ("buckets", "rows"):
+            raise ValueError("shard must be 'buckets' or 'rows'")
         self.group = group
-        kw.setdefault("stats_scale", dist.get_world_size(group) if dist.is_initialized() else 1)
-        self.local = Indexer(hashing, local_corpus_gpu, distance_func, id_base=id_base, **kw)
+        self.shard = shard
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if world == 1:
+            self.local = Indexer(hashing, local_corpus_gpu, distance_func, id_base=id_base, **kw)
+            return
+        keys, _ = hashing.hash_device(local_corpus_gpu, n=1)       # same launch the index build uses (indexer.py:36-38)
+        if shard == "buckets":
+            rows, ids, stats = exchange_rows_by_bucket(local_corpus_gpu, keys.view(-1), id_base, group)
+            self.local = Indexer(hashing, rows, distance_func, row_ids=ids, schedule_stats=stats, **kw)
+        else:
+            stats = global_statistics(keys.view(-1), group)
+            self.local = Indexer(hashing, local_corpus_gpu, distance_func, id_base=id_base, schedule_stats=stats, **kw)
 
     def query_tensors(self, query_vectors, k=10, hash_times=10, seed=0, check=True, events=None):
         """`seed` must be the same on every rank (default 0; pass a per-step value to vary probes)."""
         _, _, ncand, keys64 = self.local.query_tensors(query_vectors, k=k, hash_times=hash_times, seed=seed,
                                                        want_keys=True, check=check, events=events)
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return merge_topk_device(torch.cat([keys64, ncand.long()[:, None]], dim=1)[None], k)
         return gather_and_merge(keys64, ncand, k, self.group)

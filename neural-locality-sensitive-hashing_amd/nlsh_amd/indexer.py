@@ -85,7 +85,8 @@ def build_index(indexes, cuda=True) -> Dict[int, torch.Tensor]:
 class Indexer:
 
     def __init__(self, hashing, candidate_vectors_gpu, distance_func, compat=True, metric: Optional[str] = None,
-                 seg_rows: int = 0, id_base: int = 0, algo: Optional[str] = None, stats_scale: float = 1.0):
+                 seg_rows: int = 0, id_base: int = 0, algo: Optional[str] = None, stats_scale: float = 1.0,
+                 row_ids: Optional[torch.Tensor] = None, schedule_stats: Optional[Tuple[float, float]] = None):
         self._hashing = hashing
         self._candidate_vectors_gpu = candidate_vectors_gpu
         self._distance_func = distance_func
@@ -96,7 +97,13 @@ class Indexer:
         # number of equal shards the full corpus was split into: the schedule is chosen from the statistics of
         # the WHOLE corpus, so every shard count runs the same arithmetic and results stay bit-identical
         self.stats_scale = float(stats_scale)
+        # exact form of the same idea: (size-biased bucket size, row count) of the WHOLE corpus, as the sharded
+        # builds compute them from the all-gathered keys; overrides stats_scale when given
+        self.schedule_stats = schedule_stats
         self.id_base = int(id_base)
+        # global row id of every local row (int32 [N], device) when the shard is not a contiguous range
+        # (bucket-sharded corpus); default: id_base + local row
+        self.row_ids = row_ids
         self._index2row = None
         self._perm_host = None
         self._ws = None
@@ -125,6 +132,19 @@ class Indexer:
         _capi.check(L.nlsh_gather_rows(_capi.ptr(corpus), corpus.stride(0) if N else d, d, _capi.ptr(self.perm), N,
                                        _capi.ptr(self.corpus_sorted), self.row_stride, _capi.ptr(self.inv_norm),
                                        _capi.ptr(self.gid), self.id_base, _stream(dev)))
+        if self.row_ids is not None:
+            if self.row_ids.shape[0] != N or self.row_ids.dtype != torch.int32:
+                raise ValueError("row_ids must be int32 [N]")
+            self.gid = self.row_ids[self.perm.long()].contiguous()
+        # schedule order of the buckets (largest first) for the bucket-major scans: static per index
+        self.bucket_order = torch.empty((max(self.n_buckets, 1),), dtype=torch.int32, device=dev)
+        if self.n_buckets:
+            ob = L.nlsh_bucket_order_workspace(self.n_buckets)
+            if ob == 0:
+                _capi.check(_capi.E_HIP)
+            ows = torch.empty((ob,), dtype=torch.uint8, device=dev)
+            _capi.check(L.nlsh_bucket_order(_capi.ptr(self.offsets), self.n_buckets, _capi.ptr(self.bucket_order), _capi.ptr(ows),
+                                            ob, _stream(dev)))
         self._uniq_host = self.uniq_keys.cpu().numpy()
         self._offs_host = self.offsets.cpu().numpy().astype(np.int64)
         self.bucket_sizes = np.diff(self._offs_host)
@@ -134,7 +154,7 @@ class Indexer:
         """Reference attribute (indexer.py:38; read by trainers/base.py:87-89): materialised lazily
         as views of one int64 copy of `perm`."""
         if self._index2row is None:
-            rows = self.perm.long() + self.id_base
+            rows = self.gid.long()
             names = self._uniq_host.astype(np.int64)
             if self._hashing.key_mode == _capi.KEY_FULL:
                 names = names & 0xFFFFFFFF
@@ -175,9 +195,12 @@ class Indexer:
         vs 0.41 / 0.52 ms)."""
         if self.algo is not None:
             return {"query": _capi.SCAN_QUERY_MAJOR, "bucket": _capi.SCAN_BUCKET_MAJOR, "tiled": _capi.SCAN_BUCKET_TILED}[self.algo]
-        n = max(float(self.bucket_sizes.sum()), 1.0)
-        e_sb = self._size_biased_bucket() * self.stats_scale
-        reuse = Q * P * e_sb / (n * self.stats_scale)
+        if self.schedule_stats is not None:
+            e_sb, n = float(self.schedule_stats[0]), max(float(self.schedule_stats[1]), 1.0)
+        else:
+            e_sb = self._size_biased_bucket() * self.stats_scale
+            n = max(float(self.bucket_sizes.sum()), 1.0) * self.stats_scale
+        reuse = Q * P * e_sb / n
         if e_sb >= 256 and reuse >= 8.0:
             return _capi.SCAN_BUCKET_TILED
         if e_sb >= 128 and reuse >= 3.0:
@@ -228,7 +251,7 @@ class Indexer:
                 self._ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
             _capi.check(L.nlsh_scan_topk(
                 _capi.ptr(self.corpus_sorted), self.row_stride, d, _capi.ptr(self.gid), _capi.ptr(self.uniq_keys),
-                _capi.ptr(self.offsets), self.n_buckets, _capi.ptr(self.inv_norm), _capi.ptr(q), q.stride(0) if Q else d, Q,
+                _capi.ptr(self.offsets), _capi.ptr(self.bucket_order), self.n_buckets, _capi.ptr(self.inv_norm), _capi.ptr(q), q.stride(0) if Q else d, Q,
                 _capi.ptr(keys), _capi.ptr(nkeys), P, k, metric, algo, seg, _capi.ptr(out_dist), _capi.ptr(out_idx),
                 _capi.ptr(out_keys), _capi.ptr(ncand), _capi.ptr(status), _capi.ptr(self._ws), self._ws.numel(), max_tasks,
                 events[0].cuda_event if events else None, events[1].cuda_event if events else None, _stream(dev)))
@@ -258,7 +281,7 @@ class Indexer:
             return []
         lo, hi = int(self._offs_host[i]), int(self._offs_host[i + 1])
         if self._perm_host is None:   # one D2H of the permutation, then every fallback list is a host slice
-            self._perm_host = self.perm.cpu().numpy().astype(np.int64) + self.id_base
+            self._perm_host = self.gid.cpu().numpy().astype(np.int64)
         return self._perm_host[lo:hi].tolist()
 
     def _to_lists(self, key_sets: Sequence[Sequence[int]], idx, ncand, k):
@@ -305,6 +328,9 @@ class Indexer:
         res, nc = self._to_lists(key_lists, idx, ncand, k)
         return res, nc, dist, idx
 
+    def _global_ids(self, local_rows):
+        return self.row_ids[local_rows].long() if self.row_ids is not None else local_rows + self.id_base
+
     def _query_generic(self, query_vectors, k, hash_times):
         """Arbitrary distance callable: the reference's gather -> callable -> topk per query
         (indexer.py:62-95) on the CSR index, with stock device ops.  Not accelerated."""
@@ -322,7 +348,7 @@ class Indexer:
             n_candidates.append(int(rows.numel()))
             if rows.numel() >= k:
                 dist = self._distance_func(query_vectors[qi], corpus[rows])
-                results.append((rows[dist.topk(k, largest=False)[1]] + self.id_base).tolist())
+                results.append(self._global_ids(rows[dist.topk(k, largest=False)[1]]).tolist())
             else:
-                results.append((chunks[-1] + self.id_base).tolist() if chunks and self.compat else (rows + self.id_base).tolist())
+                results.append(self._global_ids(chunks[-1] if chunks and self.compat else rows).tolist())
         return results, n_candidates

@@ -279,3 +279,12 @@ int oracle_num_threads(void) {
     return 1;
 #endif
 }
+
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    extern void omp_set_num_threads(int);
+    omp_set_num_threads(n > 0 ? n : 1);
+#else
+    (void)n;
+#endif
+}

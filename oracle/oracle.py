@@ -55,6 +55,10 @@ def num_threads():
     return int(lib().oracle_num_threads())
 
 
+def set_num_threads(n):
+    lib().oracle_set_num_threads(ctypes.c_int(int(n)))
+
+
 # ----------------------------------------------------------------------------- bit packing
 def pack_keys(codes, mode="ref_int16"):
     """codes int32 [B, n, H] -> int64 keys [B, n]  (nlsh/utils.pyx:6-15 | eval.py:49-53)."""

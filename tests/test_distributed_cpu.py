@@ -91,3 +91,48 @@ def test_two_rank_gloo_merge_equals_single_shard(tmp_path):
     od, oi, nc = oracle.query_batch(ox.corpus, ox.perm, ox.uniq_keys, ox.offsets, queries, keys, nk, k)
     assert np.array_equal(got["nc"], nc)
     assert np.array_equal(got["idx"], oi)          # same (distance, id) comparator -> identical lists
+
+
+# ----------------------------------------------------------------------------- bucket partition (build-time exchange)
+def _exchange_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "neural-locality-sensitive-hashing_amd")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nlsh_amd.distributed import exchange_rows_by_bucket, shard_range
+    keys_all, rows_all = _exchange_case()
+    lo, hi = shard_range(len(keys_all), rank, world)
+    rows, ids, stats = exchange_rows_by_bucket(torch.from_numpy(rows_all[lo:hi]), torch.from_numpy(keys_all[lo:hi]), lo)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rows=rows.numpy(), ids=ids.numpy(), stats=np.asarray(stats))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _exchange_case():
+    rng = np.random.default_rng(11)
+    N = 5003
+    keys = np.minimum(rng.geometric(0.02, size=N), 400).astype(np.int32) - 200       # skewed sizes, negative keys too
+    rows = np.stack([np.arange(N, dtype=np.float32), keys.astype(np.float32), rng.standard_normal(N).astype(np.float32)], 1)
+    return keys, rows
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_bucket_exchange_moves_every_bucket_whole(tmp_path, world):
+    mp.spawn(_exchange_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    from nlsh_amd.distributed import assign_buckets, corpus_statistics
+    keys_all, rows_all = _exchange_case()
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    uniq, counts = np.unique(keys_all, return_counts=True)
+    owner = assign_buckets(torch.from_numpy(counts), world).numpy()
+    want_stats = corpus_statistics(torch.from_numpy(counts))
+    all_ids = np.concatenate([p["ids"] for p in parts])
+    assert np.array_equal(np.sort(all_ids), np.arange(len(keys_all)))                 # every row exactly once
+    for r, p in enumerate(parts):
+        ids = p["ids"]
+        assert np.array_equal(p["rows"], rows_all[ids])                               # rows travel with their ids
+        assert np.all(np.diff(ids) > 0)                                               # ascending global id (stable)
+        assert np.all(owner[np.searchsorted(uniq, keys_all[ids])] == r)               # only buckets this rank owns
+        assert tuple(p["stats"]) == want_stats                                        # identical schedule statistics
+    sizes = np.array([len(p["ids"]) for p in parts])
+    assert sizes.max() <= 1.1 * sizes.mean()                                          # balanced rows

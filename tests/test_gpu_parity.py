@@ -314,10 +314,11 @@ def test_sift_small_end_to_end_g7():
 
 
 # ----------------------------------------------------------------------------- (e) shards: merge == single GPU
+@pytest.mark.parametrize("partition", ["buckets", "rows"])
 @pytest.mark.parametrize("G", [2, 3, 8])
-def test_sharded_scan_plus_merge_equals_single_index(G):
+def test_sharded_scan_plus_merge_equals_single_index(G, partition):
     from nlsh_amd.data import SIFT
-    from nlsh_amd.distributed import merge_topk_device, shard_range
+    from nlsh_amd.distributed import corpus_statistics, merge_topk_device, plan_bucket_shards, shard_range
     from nlsh_amd.indexer import Indexer
     N, Q, d, H, k, P = 30000, 200, 128, 7, 10, 6
     corpus, _, _ = synth.standardise(synth.sift_like(N, d, seed=8))
@@ -325,20 +326,53 @@ def test_sharded_scan_plus_merge_equals_single_index(G):
     corpus[100:140] = corpus[20000:20040]                          # exact ties across shards
     Ws, bs = synth.make_weights([d, 64, H], seed=8)
     hashing = make_hashing(d, (64,), H, Ws, bs)
-    qd = dev(queries)
-    single = Indexer(hashing, dev(corpus), SIFT.distance)
+    qd, cd = dev(queries), dev(corpus)
+    single = Indexer(hashing, cd, SIFT.distance)
     d1, i1, n1, _ = single.query_tensors(qd, k=k, hash_times=P, seed=77)
-    keys_all, nc_all = [], []
+    owner, stats = plan_bucket_shards(single.corpus_keys, G)        # what ShardedIndexer derives from the gathered keys
+    assert stats == corpus_statistics(torch.as_tensor(single.bucket_sizes))
+    keys_all, nc_all, seen = [], [], []
     for r in range(G):
-        lo, hi = shard_range(N, r, G)
-        sh = Indexer(hashing, dev(corpus[lo:hi]), SIFT.distance, id_base=lo, stats_scale=G)   # as ShardedIndexer does
+        if partition == "rows":
+            lo, hi = shard_range(N, r, G)
+            sh = Indexer(hashing, cd[lo:hi], SIFT.distance, id_base=lo, schedule_stats=stats)
+        else:
+            sel = torch.nonzero(owner == r).view(-1)
+            sh = Indexer(hashing, cd[sel], SIFT.distance, row_ids=sel.int(), schedule_stats=stats)
+            seen.append(set(sh.uniq_keys.cpu().tolist()))
+        assert sh.choose_algo(Q, P) == single.choose_algo(Q, P)
         _, _, nc, k64 = sh.query_tensors(qd, k=k, hash_times=P, seed=77, want_keys=True)
         keys_all.append(k64); nc_all.append(nc)
+    if partition == "buckets":                                      # every bucket lives whole on exactly one rank
+        assert sum(len(s_) for s_ in seen) == single.n_buckets and len(set().union(*seen)) == single.n_buckets
     packed = torch.cat([torch.stack(keys_all), torch.stack(nc_all).long()[:, :, None]], dim=2)
     dm, im, nm = merge_topk_device(packed, k)
     assert torch.equal(nm, n1)                                      # candidate counts add up exactly
     assert torch.equal(im, i1)                                      # same comparator -> identical ids
     assert torch.equal(dm, d1)                                      # and bit-identical distances
+
+
+def test_bucket_shard_keeps_reference_views():
+    """index2row / the F7 fallback of a bucket shard speak GLOBAL row ids."""
+    from nlsh_amd.data import SIFT
+    from nlsh_amd.distributed import plan_bucket_shards
+    from nlsh_amd.indexer import Indexer
+    N, d, H = 5000, 128, 6
+    corpus, _, _ = synth.standardise(synth.sift_like(N, d, seed=18))
+    Ws, bs = synth.make_weights([d, 64, H], seed=18)
+    hashing = make_hashing(d, (64,), H, Ws, bs)
+    cd = dev(corpus)
+    single = Indexer(hashing, cd, SIFT.distance)
+    owner, stats = plan_bucket_shards(single.corpus_keys, 2)
+    merged = {}
+    for r in range(2):
+        sel = torch.nonzero(owner == r).view(-1)
+        sh = Indexer(hashing, cd[sel], SIFT.distance, row_ids=sel.int(), schedule_stats=stats)
+        for key, rows in sh.index2row.items():
+            assert key not in merged
+            merged[key] = rows.cpu().tolist()
+            assert sh._rows_of_key(key) == merged[key]
+    assert merged == {k_: v.cpu().tolist() for k_, v in single.index2row.items()}
 
 
 def test_both_schedules_are_bit_identical():

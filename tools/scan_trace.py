@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Phase timeline of the tiled scan's workgroups (diagnostic).  Needs the library built with
+`make -C neural-locality-sensitive-hashing_amd/csrc EXTRA=-DNLSH_SCAN_TRACE`.  Runs the headline workload once
+and prints, over all tasks, the mean / total wall-clock (100 MHz ticks) wave 0 spent per phase."""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "neural-locality-sensitive-hashing_amd")):
+    sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from nlsh_amd import _capi, io, synth  # noqa: E402
+from nlsh_amd.data import SIFT  # noqa: E402
+from nlsh_amd.indexer import Indexer  # noqa: E402
+
+N, d, Q = 1_000_000, 128, 10_000
+corpus_h, mean, std = synth.standardise(synth.sift_manifold(N, d, seed=synth.SEED_DATA))
+queries_h, _, _ = synth.standardise(synth.sift_manifold(Q, d, seed=synth.SEED_QUERY), mean, std)
+Ws, bs = io.load_hasher_weights(os.path.join(ROOT, "neural-locality-sensitive-hashing_amd", "checkpoints", "sift1m_manifold_h16.npz"))
+hashing = io.hashing_from_weights(Ws, bs, compat=True)
+indexer = Indexer(hashing, torch.from_numpy(corpus_h).cuda(), SIFT.distance)
+queries = torch.from_numpy(queries_h).cuda()
+for i in range(3):
+    indexer.query_tensors(queries, k=10, hash_times=10, seed=7)
+torch.cuda.synchronize()
+n_tasks = int(indexer.last_status.cpu()[0])
+L = _capi.lib()
+buf = np.zeros((min(n_tasks, 1 << 16), 8), dtype=np.float32)
+rc = L.nlsh_debug_scan_trace(buf.ctypes.data_as(ctypes.c_void_p), int(buf.size))
+assert rc == 0, rc
+names = ["total", "prologue", "stage(barriers+lds write)", "compute", "start stamp (24 bit)", "select", "nq", "nrows"]
+print(f"tasks {n_tasks}")
+for i, nm in enumerate(names):
+    print(f"  {nm:28s} mean {buf[:, i].mean():9.1f}   sum {buf[:, i].sum():12.0f}")
+full = buf[(buf[:, 6] == 16) & (buf[:, 7] == 256)]
+print(f"full tasks (16 queries x 256 rows): {len(full)}")
+for i, nm in enumerate(names[:6]):
+    print(f"  {nm:28s} mean {full[:, i].mean():9.1f}")
+
+# concurrency over time: workgroups in flight per 10 us bucket (start stamps are device-wide 100 MHz ticks)
+start = buf[:, 4].astype(np.int64)
+start = (start - start.min()) % (1 << 24)
+end = start + buf[:, 0].astype(np.int64)
+span = int(end.max())
+edges = np.arange(0, span + 1000, 1000)
+busy = np.zeros(len(edges) - 1)
+for s0, e0 in zip(start, end):
+    a, b = s0 // 1000, min(e0 // 1000, len(busy) - 1)
+    busy[a:b + 1] += 1
+print(f"kernel span {span / 100:.1f} us; workgroups in flight per 10 us slice (1024 = 4 per CU):")
+print(" ".join(f"{int(v)}" for v in busy))
+order = np.argsort(start)
+print("first/last task start (us):", start[order[0]] / 100, start[order[-1]] / 100, " last end:", end.max() / 100)
