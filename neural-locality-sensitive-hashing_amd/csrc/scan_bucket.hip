@@ -36,19 +36,10 @@ extern "C" int nlsh_debug_scan_trace(float *host, int n_floats) {
 #define SCAN_NOW() 0ull
 #endif
 
-// 1 = branch-free k-block bodies specialised on (queries, tiles) per wave with hand-placed double buffering
-// (kblock_compute); measured slower at full size than the guarded generic loop (0.434 vs 0.417 ms: 137 VGPRs ->
-// 3 waves/SIMD instead of 4, 16 loop bodies in the instruction cache), faster on small shards (0.084 vs 0.089)
-#ifndef NLSH_KBLOCK_SPECIALISED
-#define NLSH_KBLOCK_SPECIALISED 0
-#endif
-
+// 16-byte chunks per k-block of the tiled schedule.  4 (64 bytes of every row per stage): 20 KB of LDS and 64 VGPRs
+// per workgroup -> 6-7 workgroups per CU; 8 measured 0.404 ms against 0.350 ms at 4 waves/SIMD, 2 the same as 4.
 #ifndef NLSH_TILED_KB
 #define NLSH_TILED_KB 4
-#endif
-
-#ifndef NLSH_ROW_PREFETCH
-#define NLSH_ROW_PREFETCH 0
 #endif
 
 #ifndef NLSH_ABLATE
@@ -337,15 +328,24 @@ __global__ __launch_bounds__(256) void bscan2_kernel(BArgs a) {
 }
 
 // ------------------------------------------------------------------------------------ tiled variant
-// NLSH_SCAN_BUCKET_TILED: one WORKGROUP per task = (bucket segment, group of <= 32 queries).
-// The 64-row tile is staged once through LDS (coalesced 16-byte global loads -> ds_write_b128, row
-// stride 33 slots = conflict-free column reads) and every lane then OWNS ONE ROW: it walks the row
-// in k order and updates 8 query accumulators per wave, the query values arriving as wave-uniform
-// scalar loads (s_load from a padded, pre-normalised copy of the queries).  No cross-lane reduction
-// at all: 3 VALU per element and query for L2 ((q-c), +eps, fma), 1 for cosine; the distance of
-// lane l's row is a k-ascending fmaf chain, bit-identical to the oracle's scalar loop.  Four waves
-// share the tile, so a row is fetched from HBM/L2 once per 32 queries.  The next stage's global
-// loads are issued before the current stage is computed (T14 split: load early, ds_write late).
+// NLSH_SCAN_BUCKET_TILED: one WORKGROUP per task = (256-row bucket segment, group of <= 16 queries).
+// The segment goes through LDS one k-block (KB 16-byte chunks of every row) at a time (coalesced 16-byte
+// global loads -> ds_write_b128, odd row stride = conflict-free column reads) and every lane OWNS ONE ROW of
+// each 64-row tile: it walks the row in k order and updates QW query accumulators per tile, the query values
+// arriving as wave-uniform scalar loads (s_load from the queries, or from a padded / pre-normalised copy when
+// bprep is needed).  No cross-lane reduction at all: 3 VALU per element and query for L2 ((q-c), +eps, fma),
+// 1 for cosine; the distance of lane l's row is a k-ascending fmaf chain, bit-identical to the oracle's scalar
+// loop.  Four waves share the tile, so a row is fetched from HBM/L2 once per 16 queries.  The next k-block's
+// global loads are issued before the current one is computed (load early, ds_write late).
+//
+// What bounds it (r01 traces, tools/scan_trace.py, tools/probe_l2_loop.hip): the inner loop's instruction mix
+// sustains 1 VALU / 2.5-2.9 cycles per SIMD in isolation; the kernel reaches ~60 % of that because a wave spends
+// ~35 % of a task outside the distance loop (stage barriers, top-k selection) and only resident waves of OTHER
+// workgroups fill those gaps -- occupancy is the lever that paid (KB 8 -> 4: 4 -> 6-7 workgroups per CU, 0.40 ->
+// 0.34 ms).  Measured and dropped: branch-free loop bodies specialised on (queries, tiles) per wave, with and
+// without hand-placed LDS/SMEM double buffering (the scheduler keeps the scalar query chunks in VGPRs: 110-150
+// VGPRs, 3-4 waves/SIMD, 0.43-0.49 ms); reading the next step's row chunk one step ahead (+3 %); reading all
+// tiles' chunks of a step up front (+-0).
 typedef const __attribute__((address_space(4))) float *const_f32p;
 
 __global__ __launch_bounds__(64) void bprep_kernel(BArgs a, int metric) {
@@ -378,23 +378,8 @@ __device__ __forceinline__ void load_qchunk(QChunk<QW> &qc, const const_f32p (&q
         }
 }
 
-template <int METRIC, int QW, int NQ>
-__device__ __forceinline__ void apply_qchunk(const QChunk<NQ> &qc, const float4 rv, float (&acc)[QW]) {
-#pragma unroll
-    for (int jq = 0; jq < NQ; ++jq) {
-        const float q0 = qc.v[jq][0], q1 = qc.v[jq][1], q2 = qc.v[jq][2], q3 = qc.v[jq][3];
-        if (METRIC == NLSH_METRIC_L2_EPS) {
-            // F.pairwise_distance: || (x1 - x2) + eps ||, summed in k order (nlsh/data.py:201)
-            const float t0 = (q0 - rv.x) + 1e-6f, t1 = (q1 - rv.y) + 1e-6f, t2 = (q2 - rv.z) + 1e-6f, t3 = (q3 - rv.w) + 1e-6f;
-            acc[jq] = fmaf(t3, t3, fmaf(t2, t2, fmaf(t1, t1, fmaf(t0, t0, acc[jq]))));
-        } else {
-            acc[jq] = fmaf(q3, rv.w, fmaf(q2, rv.z, fmaf(q1, rv.y, fmaf(q0, rv.x, acc[jq]))));
-        }
-    }
-}
-
 template <int METRIC, int QW, bool FULL>
-__device__ __forceinline__ void apply_qchunk_guarded(const QChunk<QW> &qc, const float4 rv, int nqw, float (&acc)[QW]) {
+__device__ __forceinline__ void apply_qchunk(const QChunk<QW> &qc, const float4 rv, int nqw, float (&acc)[QW]) {
 #pragma unroll
     for (int jq = 0; jq < QW; ++jq) {
         if (FULL || jq < nqw) {
@@ -408,126 +393,6 @@ __device__ __forceinline__ void apply_qchunk_guarded(const QChunk<QW> &qc, const
             }
         }
     }
-}
-
-// s_waitcnt lgkmcnt(0) only (vmcnt / expcnt untouched): gfx9 encoding vmcnt[3:0]|expcnt[6:4]|lgkmcnt[11:8]|vmcnt_hi[15:14]
-#define NLSH_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
-
-// One k-block (<= KB 16-byte chunks) of NQ queries x NTL row tiles, BRANCH-FREE (the counts are template
-// parameters, bscan3 dispatches on them once per k-block).  Both operand streams are double buffered by hand:
-// the wait for chunk c's operands (LDS rows + scalar-loaded queries share lgkmcnt, and SMEM returns out of
-// order, so it is always lgkmcnt(0)) is placed BEFORE chunk c+1's loads are issued; those then fly under
-// chunk c's NQ*NTL*12 VALU instructions.  (The guarded generic body it replaces issued each ds_read_b128
-// right before its use, behind a scalar branch: the LDS round trip was exposed once per tile and chunk.)
-template <int METRIC, int QW, int TPS, int RS, int NQ, int NTL>
-__device__ __forceinline__ void kblock_compute(const float4 *col, const const_f32p (&qk)[QW], int nchunk, float (&acc)[TPS][QW]) {
-    const_f32p qn[NQ];
-#pragma unroll
-    for (int jq = 0; jq < NQ; ++jq) qn[jq] = qk[jq];
-    QChunk<NQ> qa, qb;
-    float4 ra[NTL], rb[NTL];
-    load_qchunk<NQ, true>(qa, qn, NQ, 0);
-#pragma unroll
-    for (int tl = 0; tl < NTL; ++tl) ra[tl] = col[tl * 64 * RS];
-    for (int c = 0; c < nchunk; c += 2) {
-        const int c1 = min(c + 1, nchunk - 1);
-        NLSH_WAIT_LGKM0();
-        load_qchunk<NQ, true>(qb, qn, NQ, c1);
-#pragma unroll
-        for (int tl = 0; tl < NTL; ++tl) rb[tl] = col[tl * 64 * RS + c1];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int tl = 0; tl < NTL; ++tl) {
-            apply_qchunk<METRIC, QW, NQ>(qa, ra[tl], acc[tl]);
-            __builtin_amdgcn_sched_barrier(0);  // one tile's temporaries at a time (register pressure -> 4 waves/SIMD)
-        }
-        if (c + 1 >= nchunk) break;
-        const int c2 = min(c + 2, nchunk - 1);
-        NLSH_WAIT_LGKM0();
-        load_qchunk<NQ, true>(qa, qn, NQ, c2);
-#pragma unroll
-        for (int tl = 0; tl < NTL; ++tl) ra[tl] = col[tl * 64 * RS + c2];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int tl = 0; tl < NTL; ++tl) {
-            apply_qchunk<METRIC, QW, NQ>(qb, rb[tl], acc[tl]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
-// The full wave (QW queries x TPS tiles) without guards and without hand-placed buffering: the query chunks go
-// through two scalar register sets as in the generic loop, the TPS row chunks are read at the top of each step.
-template <int METRIC, int QW, int TPS, int RS>
-__device__ __forceinline__ void kblock_full(const float4 *col, const const_f32p (&qk)[QW], int nchunk, float (&acc)[TPS][QW]) {
-    QChunk<QW> qa, qb;
-    load_qchunk<QW, true>(qa, qk, QW, 0);
-    for (int c = 0; c < nchunk; c += 2) {
-        const bool has1 = c + 1 < nchunk;
-        load_qchunk<QW, true>(qb, qk, QW, has1 ? c + 1 : c);
-#pragma unroll
-        for (int tl = 0; tl < TPS; ++tl) apply_qchunk<METRIC, QW, QW>(qa, col[tl * 64 * RS + c], acc[tl]);
-        if (!has1) break;
-        load_qchunk<QW, true>(qa, qk, QW, c + 2 < nchunk ? c + 2 : c);
-#pragma unroll
-        for (int tl = 0; tl < TPS; ++tl) apply_qchunk<METRIC, QW, QW>(qb, col[tl * 64 * RS + c + 1], acc[tl]);
-    }
-}
-
-// The full wave again, branch-free but in the generic loop's strict (tile, query) order: a scheduling barrier after
-// every query's 12 instructions keeps the live temporaries at 4 registers (left alone, the scheduler interleaves
-// the 16 blocks for ILP and the kernel needs ~120 VGPRs: 4 waves/SIMD instead of 7).
-template <int METRIC, int QW, int TPS, int RS>
-__device__ __forceinline__ void kblock_full_ordered(const float4 *col, const const_f32p (&qk)[QW], int nchunk, float (&acc)[TPS][QW]) {
-    QChunk<QW> qa, qb;
-    load_qchunk<QW, true>(qa, qk, QW, 0);
-    auto step = [&](const QChunk<QW> &qc, int c) {
-#pragma unroll
-        for (int tl = 0; tl < TPS; ++tl) {
-            const float4 rv = col[tl * 64 * RS + c];
-#pragma unroll
-            for (int jq = 0; jq < QW; ++jq) {
-                const float q0 = qc.v[jq][0], q1 = qc.v[jq][1], q2 = qc.v[jq][2], q3 = qc.v[jq][3];
-                if (METRIC == NLSH_METRIC_L2_EPS) {
-                    const float t0 = (q0 - rv.x) + 1e-6f, t1 = (q1 - rv.y) + 1e-6f, t2 = (q2 - rv.z) + 1e-6f, t3 = (q3 - rv.w) + 1e-6f;
-                    acc[tl][jq] = fmaf(t3, t3, fmaf(t2, t2, fmaf(t1, t1, fmaf(t0, t0, acc[tl][jq]))));
-                } else {
-                    acc[tl][jq] = fmaf(q3, rv.w, fmaf(q2, rv.z, fmaf(q1, rv.y, fmaf(q0, rv.x, acc[tl][jq]))));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-    for (int c = 0; c < nchunk; c += 2) {
-        const bool has1 = c + 1 < nchunk;
-        load_qchunk<QW, true>(qb, qk, QW, has1 ? c + 1 : c);
-        __builtin_amdgcn_sched_barrier(0);
-        step(qa, c);
-        if (!has1) break;
-        load_qchunk<QW, true>(qa, qk, QW, c + 2 < nchunk ? c + 2 : c);
-        __builtin_amdgcn_sched_barrier(0);
-        step(qb, c + 1);
-    }
-}
-
-template <int METRIC, int QW, int TPS, int RS, int NTL>
-__device__ __forceinline__ void kblock_by_queries(int nqw, const float4 *col, const const_f32p (&qk)[QW], int nchunk, float (&acc)[TPS][QW]) {
-    static_assert(QW == 4, "dispatch below enumerates 1..4 queries per wave");
-    switch (nqw) {
-    case 1: kblock_compute<METRIC, QW, TPS, RS, 1, NTL>(col, qk, nchunk, acc); break;
-    case 2: kblock_compute<METRIC, QW, TPS, RS, 2, NTL>(col, qk, nchunk, acc); break;
-    case 3: kblock_compute<METRIC, QW, TPS, RS, 3, NTL>(col, qk, nchunk, acc); break;
-    default: kblock_compute<METRIC, QW, TPS, RS, 4, NTL>(col, qk, nchunk, acc); break;
-    }
-}
-
-template <int METRIC, int QW, int TPS, int RS>
-__device__ __forceinline__ void kblock_dispatch(int nqw, int ntile, const float4 *col, const const_f32p (&qk)[QW], int nchunk, float (&acc)[TPS][QW]) {
-    static_assert(TPS == 4 || TPS == 2 || TPS == 1, "dispatch below enumerates up to 4 tiles");
-    if (TPS >= 4 && ntile >= 4) kblock_by_queries<METRIC, QW, TPS, RS, (TPS >= 4 ? 4 : TPS)>(nqw, col, qk, nchunk, acc);
-    else if (TPS >= 4 && ntile == 3) kblock_by_queries<METRIC, QW, TPS, RS, (TPS >= 4 ? 3 : TPS)>(nqw, col, qk, nchunk, acc);
-    else if (TPS >= 2 && ntile >= 2) kblock_by_queries<METRIC, QW, TPS, RS, (TPS >= 2 ? 2 : TPS)>(nqw, col, qk, nchunk, acc);
-    else kblock_by_queries<METRIC, QW, TPS, RS, 1>(nqw, col, qk, nchunk, acc);
 }
 
 // QW queries per wave, NW waves per workgroup (QW*NW queries per task), TPS 64-row tiles per task.
@@ -618,66 +483,21 @@ __global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
             const_f32p qk[QW];
 #pragma unroll
             for (int jq = 0; jq < QW; ++jq) qk[jq] = qs[jq] + kb * KB * 4;
-#if NLSH_KBLOCK_SPECIALISED == 2
-            kblock_dispatch<METRIC, QW, TPS, RS>(nqw, ntile, tile + lane * RS, qk, nchunk, acc);
-#else
-            if (NLSH_KBLOCK_SPECIALISED == 1 && nqw == QW && ntile == TPS) {
-                // the full (QW queries x TPS tiles) wave: 65 % of the tile-query work of the headline run
-                kblock_compute<METRIC, QW, TPS, RS, QW, TPS>(tile + lane * RS, qk, nchunk, acc);
-            } else if (NLSH_KBLOCK_SPECIALISED == 3 && nqw == QW && ntile == TPS) {
-                kblock_full<METRIC, QW, TPS, RS>(tile + lane * RS, qk, nchunk, acc);
-            } else if (NLSH_KBLOCK_SPECIALISED == 4 && nqw == QW && ntile == TPS) {
-                kblock_full_ordered<METRIC, QW, TPS, RS>(tile + lane * RS, qk, nchunk, acc);
-            } else {
             const float4 *col = tile + lane * RS;
             QChunk<QW> qa, qb;
             load_qchunk<QW, false>(qa, qk, nqw, 0);
-#if NLSH_ROW_PREFETCH
-            // The row chunk of the NEXT (chunk, tile) step is read from LDS before the current step's math, so its
-            // round trip hides under the step's <= QW*12 VALU instructions (read right before its use it was
-            // exposed once per tile and chunk: ~128 LDS round trips per task and wave).
-            float4 rcur = col[0];
             for (int c = 0; c < nchunk; c += 2) {
                 const bool has1 = c + 1 < nchunk;
                 load_qchunk<QW, false>(qb, qk, nqw, has1 ? c + 1 : c);
 #pragma unroll
                 for (int tl = 0; tl < TPS; ++tl)
-                    if (tl < ntile) {
-                        const bool wrap = tl + 1 >= ntile;
-                        const float4 rnext = col[(wrap ? 0 : tl + 1) * 64 * RS + (wrap && has1 ? c + 1 : c)];
-                        __builtin_amdgcn_sched_barrier(0);
-                        apply_qchunk_guarded<METRIC, QW, false>(qa, rcur, nqw, acc[tl]);
-                        rcur = rnext;
-                    }
-                if (!has1) break;
-                const bool has2 = c + 2 < nchunk;
-                load_qchunk<QW, false>(qa, qk, nqw, has2 ? c + 2 : c);
-#pragma unroll
-                for (int tl = 0; tl < TPS; ++tl)
-                    if (tl < ntile) {
-                        const bool wrap = tl + 1 >= ntile;
-                        const float4 rnext = col[(wrap ? 0 : tl + 1) * 64 * RS + (wrap && has2 ? c + 2 : c + 1)];
-                        __builtin_amdgcn_sched_barrier(0);
-                        apply_qchunk_guarded<METRIC, QW, false>(qb, rcur, nqw, acc[tl]);
-                        rcur = rnext;
-                    }
-            }
-#else
-            for (int c = 0; c < nchunk; c += 2) {
-                const bool has1 = c + 1 < nchunk;
-                load_qchunk<QW, false>(qb, qk, nqw, has1 ? c + 1 : c);
-#pragma unroll
-                for (int tl = 0; tl < TPS; ++tl)
-                    if (tl < ntile) apply_qchunk_guarded<METRIC, QW, false>(qa, col[tl * 64 * RS + c], nqw, acc[tl]);
+                    if (tl < ntile) apply_qchunk<METRIC, QW, false>(qa, col[tl * 64 * RS + c], nqw, acc[tl]);
                 if (!has1) break;
                 load_qchunk<QW, false>(qa, qk, nqw, c + 2 < nchunk ? c + 2 : c);
 #pragma unroll
                 for (int tl = 0; tl < TPS; ++tl)
-                    if (tl < ntile) apply_qchunk_guarded<METRIC, QW, false>(qb, col[tl * 64 * RS + c + 1], nqw, acc[tl]);
+                    if (tl < ntile) apply_qchunk<METRIC, QW, false>(qb, col[tl * 64 * RS + c + 1], nqw, acc[tl]);
             }
-#endif
-            }
-#endif
         }
 #ifdef NLSH_SCAN_TRACE
         {   // the accumulators must exist before the stamp: make the stamp depend on one of them

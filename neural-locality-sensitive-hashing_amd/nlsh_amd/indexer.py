@@ -106,7 +106,7 @@ class Indexer:
         self.row_ids = row_ids
         self._index2row = None
         self._perm_host = None
-        self._ws = None
+        self._ws = {}               # scan workspace per stream (concurrent query batches on different HIP streams)
         self._max_tasks = {}
         self._build_index()
 
@@ -247,14 +247,16 @@ class Indexer:
         while True:
             max_tasks = self._max_tasks[algo]
             ws_bytes = L.nlsh_scan_workspace(Q, P, k, max_tasks, self.n_buckets, d)
-            if self._ws is None or self._ws.numel() < ws_bytes or self._ws.device != dev:
-                self._ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
+            stream = _stream(dev)
+            ws = self._ws.get(stream)
+            if ws is None or ws.numel() < ws_bytes or ws.device != dev:
+                ws = self._ws[stream] = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
             _capi.check(L.nlsh_scan_topk(
                 _capi.ptr(self.corpus_sorted), self.row_stride, d, _capi.ptr(self.gid), _capi.ptr(self.uniq_keys),
                 _capi.ptr(self.offsets), _capi.ptr(self.bucket_order), self.n_buckets, _capi.ptr(self.inv_norm), _capi.ptr(q), q.stride(0) if Q else d, Q,
                 _capi.ptr(keys), _capi.ptr(nkeys), P, k, metric, algo, seg, _capi.ptr(out_dist), _capi.ptr(out_idx),
-                _capi.ptr(out_keys), _capi.ptr(ncand), _capi.ptr(status), _capi.ptr(self._ws), self._ws.numel(), max_tasks,
-                events[0].cuda_event if events else None, events[1].cuda_event if events else None, _stream(dev)))
+                _capi.ptr(out_keys), _capi.ptr(ncand), _capi.ptr(status), _capi.ptr(ws), ws.numel(), max_tasks,
+                events[0].cuda_event if events else None, events[1].cuda_event if events else None, stream))
             if not check or Q == 0:
                 break
             needed, overflow = status.cpu().tolist()
