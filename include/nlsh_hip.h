@@ -49,7 +49,8 @@ enum { NLSH_SCAN_QUERY_MAJOR = 0, NLSH_SCAN_BUCKET_MAJOR = 1, NLSH_SCAN_BUCKET_T
 
 #define NLSH_MAX_LAYERS 8   /* Linear layers incl. the output layer */
 #define NLSH_MAX_HASH_BITS 32
-#define NLSH_MAX_PROBES 64  /* hash_times */
+#define NLSH_MAX_PROBES 64  /* keys per query one nlsh_scan_topk call takes */
+#define NLSH_MAX_ENCODE_PROBES 128  /* hash_times nlsh_encode_hash generates (eval.py:148 sweeps 1..100); scan in slices of 64 */
 #define NLSH_MAX_K 64
 #define NLSH_MAX_DIM 1024   /* vector dimension of corpus / queries for the scan */
 #define NLSH_MAX_WIDTH 632  /* widest encoder layer (input, hidden) the LDS-resident MLP supports */
@@ -85,7 +86,7 @@ int nlsh_encoder_pack(int n_layers, const int *dims, const float *const *W, cons
  * Probes 1..n_probes-1 are Bernoulli(p) draws from a Philox4x32-10 stream keyed by `seed`,
  * counter (row0 + row, probe, word): reproducible across devices and ranks.  Rows with index
  * >= n_multi_rows are single-probe (Indexer.hash's trailing-batch rule, nlsh/indexer.py:51-53).
- * Limits: H <= 32, n_probes <= NLSH_MAX_PROBES, every dims[l] (l < n_layers) <= NLSH_MAX_WIDTH. */
+ * Limits: H <= 32, n_probes <= NLSH_MAX_ENCODE_PROBES, every dims[l] (l < n_layers) <= NLSH_MAX_WIDTH. */
 int nlsh_encode_hash(const float *x, int64_t n, int64_t x_stride, int n_layers, const int *dims,
                      const float *packed, int act, int key_mode, int n_probes, int64_t n_multi_rows,
                      uint64_t seed, int64_t row0, float *z_out, float *probs_out, uint32_t *code_out,

@@ -473,7 +473,7 @@ extern "C" int nlsh_encode_hash(const float *x, int64_t n, int64_t x_stride, int
     NLSH_REQUIRE(act == NLSH_ACT_SIGMOID || act == NLSH_ACT_TANH, NLSH_E_INVALID, "encode_hash: act=%d", act);
     NLSH_REQUIRE(key_mode == NLSH_KEY_REF_INT16 || key_mode == NLSH_KEY_FULL, NLSH_E_INVALID, "encode_hash: key_mode=%d", key_mode);
     // hashings.py:83: "`n` should be positive integer"
-    NLSH_REQUIRE(n_probes >= 1 && n_probes <= NLSH_MAX_PROBES, NLSH_E_INVALID, "encode_hash: n_probes=%d not in [1,%d]", n_probes, NLSH_MAX_PROBES);
+    NLSH_REQUIRE(n_probes >= 1 && n_probes <= NLSH_MAX_ENCODE_PROBES, NLSH_E_INVALID, "encode_hash: n_probes=%d not in [1,%d]", n_probes, NLSH_MAX_ENCODE_PROBES);
 
     EncArgs a;
     a.x = x; a.n = n; a.x_stride = x_stride; a.n_layers = n_layers; a.packed = packed;
@@ -481,6 +481,7 @@ extern "C" int nlsh_encode_hash(const float *x, int64_t n, int64_t x_stride, int
     fill_layers(n_layers, dims, a.L, &total);
     int maxKp = 64;
     for (int l = 0; l < n_layers; ++l) if (a.L[l].Kp > maxKp) maxKp = a.L[l].Kp;
+    if (round_up(n_probes, 8) > maxKp) maxKp = round_up(n_probes, 8);  // the per-row key table [M][n_probes] reuses an activation image
     a.S = maxKp + 4;  // S/4 odd -> conflict-free ds_read_b128 of A fragments
     a.H = dims[n_layers]; a.act = act; a.key_mode = key_mode; a.n_probes = n_probes;
     a.n_multi_rows = n_multi_rows; a.row0 = row0; a.seed = seed;
@@ -488,7 +489,8 @@ extern "C" int nlsh_encode_hash(const float *x, int64_t n, int64_t x_stride, int
 
     hipStream_t s = (hipStream_t)stream;
     const size_t lds_limit = 160 * 1024;
-    if ((size_t)2 * 64 * a.S * 4 <= lds_limit) {  // (32-row tiles for small batches measured slower: 0.775 vs 0.762 ms/step)
+    // (32-row workgroups for query-sized batches, two per CU, measured the same step time twice: 0.455 vs 0.451 ms)
+    if ((size_t)2 * 64 * a.S * 4 <= lds_limit) {
         size_t lds = (size_t)2 * 64 * a.S * 4;
         NLSH_CHECK_HIP(hipFuncSetAttribute((const void *)encode_hash_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         long long grid = (n + 63) / 64;

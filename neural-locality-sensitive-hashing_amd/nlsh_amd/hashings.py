@@ -150,8 +150,8 @@ class MultivariateBernoulli:
     def _run(self, x, n, n_multi_rows=None, seed=None, row0=0, want_probs=False, z_out=None, code_out=None):
         if x.device.type != "cuda":
             raise _capi.NlshHipError(_capi.E_INVALID, "encode_hash needs a device tensor; there is no CPU path")
-        if n > _capi.MAX_PROBES:
-            raise _capi.NlshHipError(_capi.E_UNSUPPORTED, f"hash_times={n} > {_capi.MAX_PROBES}")
+        if n > _capi.MAX_ENCODE_PROBES:
+            raise _capi.NlshHipError(_capi.E_UNSUPPORTED, f"hash_times={n} > {_capi.MAX_ENCODE_PROBES}")
         L = _capi.lib()
         x = x.detach()
         if x.dtype != torch.float32:

@@ -231,6 +231,8 @@ class Indexer:
         if d != self.dim:
             raise ValueError(f"query dim {d} != corpus dim {self.dim}")
         dev = q.device
+        if keys.shape[1] > _capi.MAX_PROBES:
+            return self._scan_sliced(q, keys, nkeys, k, want_keys, check)
         keys = keys.contiguous()
         nkeys = nkeys.contiguous()
         P = keys.shape[1]
@@ -266,6 +268,28 @@ class Indexer:
         self.last_status = status
         self.last_algo = algo
         return out_dist, out_idx, ncand, out_keys
+
+    def _scan_sliced(self, q, keys, nkeys, k, want_keys, check):
+        """hash_times > 64 (eval.py:148 sweeps n_samples up to 100): the key table is scanned in column slices of
+        64.  A row's keys are distinct (encode_hash de-duplicates across all probes) and buckets are disjoint (F9),
+        so the slices see disjoint candidates: merging their top-k lists with the (distance, id) comparator and
+        adding their candidate counts is exact."""
+        from .distributed import merge_topk_device
+        parts, counts = [], []
+        for c0 in range(0, keys.shape[1], _capi.MAX_PROBES):
+            kc = keys[:, c0:c0 + _capi.MAX_PROBES].contiguous()
+            nk = (nkeys - c0).clamp(0, kc.shape[1]).to(torch.int32)
+            _, _, nc, k64 = self.scan_tensors(q, kc, nk, k=k, want_keys=True, check=check)
+            parts.append(k64)
+            counts.append(nc)
+        packed = torch.cat([torch.stack(parts), torch.stack(counts).long()[:, :, None]], dim=2)
+        dist, idx, ncand = merge_topk_device(packed, k)
+        keys64 = None
+        if want_keys:   # the 64-bit sort keys of the merged lists: monotone(dist) << 32 | id, ~0 for padding
+            bits = dist.view(torch.int32).long() & 0xFFFFFFFF
+            mono = torch.where(bits >= (1 << 31), (~bits) & 0xFFFFFFFF, bits | (1 << 31))
+            keys64 = torch.where(idx < 0, torch.full_like(mono, -1), (mono << 32) | (idx.long() & 0xFFFFFFFF))
+        return dist, idx, ncand, keys64
 
     def query_tensors(self, query_vectors, k=10, hash_times=10, seed=None, want_keys=False, check=True, events=None):
         """Device-resident form of `query`: hashing + scan, nothing copied to the host.

@@ -241,6 +241,40 @@ def test_scan_vs_oracle_shapes(metric, d, N, Q, H, k, seg, P, algo):
     assert exact >= 0.9 * Q                                       # id lists identical to the oracle except near-ties
 
 
+def test_hash_times_100_keys_and_sliced_scan():
+    """eval.py:148 sweeps n_samples up to 100: encode_hash generates up to 128 keys per row, the scan takes them in
+    slices of 64 and merges -- same keys as the oracle's sampler, same results as its single pass."""
+    from nlsh_amd.data import SIFT
+    from nlsh_amd.indexer import Indexer
+    d, H, N, Q, k, P = 128, 14, 30000, 96, 10, 100
+    Ws, bs = synth.make_weights([d, 64, H], seed=77)
+    corpus, _, _ = synth.standardise(synth.sift_like(N, d, seed=70))
+    queries, _, _ = synth.standardise(synth.sift_like(Q, d, seed=71))
+    hashing = make_hashing(d, (64,), H, Ws, bs, compat=False)
+    qd = dev(queries)
+    keys, nkeys = hashing.hash_device(qd, n=P, seed=5)
+    _, probs, _ = hashing.forward_device(qd)
+    ko, no = oracle.row_keys(probs.cpu().numpy(), P, "full", seed=5, n_multi_rows=Q)
+    kd = keys.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    assert np.array_equal(nkeys.cpu().numpy(), no) and no.max() > 64          # the case needs more than one slice
+    for r in range(Q):
+        assert np.array_equal(kd[r, :no[r]], ko[r, :no[r]])
+    indexer = Indexer(hashing, dev(corpus), SIFT.distance, compat=False)
+    dist, idx, nc, k64 = indexer.scan_tensors(qd, keys, nkeys, k=k, want_keys=True)
+    ck = indexer.corpus_keys.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    perm, uniq, offs = oracle.build_csr(ck)
+    od, oi, onc = oracle.query_batch(corpus, perm, uniq, offs, queries, ko, no, k, "l2")
+    assert np.array_equal(nc.cpu().numpy(), onc)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.allclose(dist.cpu().numpy(), od, rtol=2e-5, atol=0) or np.array_equal(np.isinf(dist.cpu().numpy()), np.isinf(od))
+    # the merged lists' sort keys are what a shard would all-gather: monotone(dist) << 32 | id
+    kk = k64.cpu().numpy().view(np.uint64)
+    assert np.array_equal((kk & np.uint64(0xFFFFFFFF)).astype(np.int64)[idx.cpu().numpy() >= 0], idx.cpu().numpy()[idx.cpu().numpy() >= 0])
+    assert np.all(kk[:, 1:] >= kk[:, :-1])
+    res, ncl = indexer.query(qd, k=k, hash_times=P)                            # the reference-typed call takes the same path
+    assert len(res) == Q and all(len(r) <= max(k, 1) or ncl[i] < k for i, r in enumerate(res))
+
+
 def test_scan_edge_cases():
     from nlsh_amd.data import SIFT
     from nlsh_amd.indexer import Indexer
