@@ -55,6 +55,8 @@ def parse():
                     help="N>1 partition of the corpus: whole buckets per rank (default) or contiguous row ranges")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("NLSH_BENCH_STREAMS", 1)),
                     help="HIP streams the steps are dealt to round-robin (2 = batch i+1's encode/plan overlaps batch i's scan)")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="also time the K steps dealt to two HIP streams (reported as `pipelined`, never as `value`)")
     ap.add_argument("--algo", default=None, choices=["query", "bucket", "tiled"], help="force a scan schedule (default: auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--random-init", action="store_true", help="ignore the learned-hash checkpoint")
@@ -188,7 +190,7 @@ def main():
     # batch i's scan tail overlap.  Reported beside `value`, never as `value`: kernel durations overlap in this
     # mode, so the roofline figures come from the single-stream region above.
     pipelined = None
-    if world == 1 and len(streams) == 1:
+    if args.pipelined and world == 1 and len(streams) == 1:
         two = [torch.cuda.Stream(device=dev) for _ in range(2)]
         for st in two:
             with torch.cuda.stream(st):

@@ -63,7 +63,7 @@ def main():
     print(f"# index: {indexer.bucket_stats()} built in {time.time() - t0:.3f}s", flush=True)
     print("n_samples avg_n_candidates recall qps")
     rows = []
-    for n_samples in range(1, min(args.max_samples, 64) + 1):
+    for n_samples in range(1, min(args.max_samples, 100) + 1):   # eval.py:148 range(1, 101)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         dist, idx, nc, _ = indexer.query_tensors(qg, k=args.k, hash_times=n_samples, seed=n_samples)
