@@ -68,7 +68,8 @@ struct BArgs {
     uint64_t *out_keys;
     int32_t *out_ncand;
     int32_t *status;
-    int32_t *pbkt, *pairpos, *inv_q, *bcount, *pairoff, *taskoff, *bgroups, *counters;
+    int32_t *pbkt, *inv_q, *bcount, *pairoff, *taskoff, *bgroups, *counters;
+    int4 *prec;  // [Q*P] per (query, probe): {first task of its query group, slot in the group, row segments, query groups}; .z = 0: no bucket
     int4 *task;
     uint64_t *partial;
     long long max_tasks;
@@ -212,10 +213,16 @@ __global__ __launch_bounds__(256) void bscatter_kernel(BArgs a) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= a.Q * a.P) return;
     const int b = a.pbkt[idx];
-    if (b < 0) return;
-    const int pos = a.pairoff[b] + atomicSub(&a.bcount[b], 1) - 1;
-    a.inv_q[pos] = (int32_t)(idx / a.P);
-    a.pairpos[idx] = pos;
+    if (b < 0) {
+        a.prec[idx] = make_int4(0, 0, 0, 0);
+        return;
+    }
+    const int rel = atomicSub(&a.bcount[b], 1) - 1;  // slot of this query in the bucket's pair list
+    a.inv_q[a.pairoff[b] + rel] = (int32_t)(idx / a.P);
+    // what bmerge needs to find this probe's partial lists, resolved here so that it has one load level less:
+    // task of (segment si, group gi) = taskoff + si * ngroups + gi
+    const int gi = rel / a.QB;
+    a.prec[idx] = make_int4(a.taskoff[b] + gi, rel - gi * a.QB, (a.offsets[b + 1] - a.offsets[b] + a.seg - 1) / a.seg, a.bgroups[b]);
 }
 
 // One task: stream `nrows` rows starting at row0 once, score them against the nq <= QB queries of
@@ -568,32 +575,42 @@ __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
     int nk = __builtin_amdgcn_readfirstlane(a.nkeys[q]);
     nk = nk < 0 ? 0 : (nk > a.P ? a.P : nk);
     uint64_t top = KEY_NONE, tau = KEY_NONE;
-    // lane p resolves probe p (all the dependent index loads of the nk probes overlap), then the
-    // wave walks the partial lists with the per-probe values broadcast by v_readlane
+    // lane p holds probe p's record (written by bscatter): where its partial lists are
     int ns_l = 0, j_l = 0, ng_l = 0;
     long long t0_l = 0;
     if (lane < nk) {
-        const int b = a.pbkt[q * a.P + lane];
-        if (b >= 0) {
-            const int rel = a.pairpos[q * a.P + lane] - a.pairoff[b];
-            const int gi = rel / a.QB;
-            j_l = rel - gi * a.QB;
-            ns_l = (a.offsets[b + 1] - a.offsets[b] + a.seg - 1) / a.seg;
-            ng_l = a.bgroups[b];
-            t0_l = (long long)a.taskoff[b] + gi;  // task of (segment si, group gi) = taskoff + si * ngroups + gi
-        }
+        const int4 rec = a.prec[q * a.P + lane];
+        t0_l = rec.x; j_l = rec.y; ns_l = rec.z; ng_l = rec.w;
     }
-    for (int p = 0; p < nk; ++p) {
-        const int ns = __builtin_amdgcn_readlane(ns_l, p);
-        const int j = __builtin_amdgcn_readlane(j_l, p);
-        const int ng = __builtin_amdgcn_readlane(ng_l, p);
-        const long long t0 = (long long)read_lane64((uint64_t)t0_l, p);
-        for (int si = 0; si < ns; ++si) {
-            const long long t = t0 + (long long)si * ng;
-            if (t >= a.max_tasks) break;  // overflow: status[1] set by the scan kernel
-            const uint64_t key = lane < a.k ? a.partial[(t * a.QB + j) * a.k + lane] : KEY_NONE;
-            topk_offer(top, tau, key, a.k, lane);
+    // The query's partial lists (one per probe and row segment) are numbered 0..L-1 by an inclusive scan of the
+    // per-probe segment counts.  R = 64/k lists are fetched per round with ONE load instruction (lane -> (list,
+    // entry)): L/R dependent memory round trips instead of L, which is what this kernel's time was.
+    int incl = ns_l;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const int up = __shfl_up(incl, m);
+        if (lane >= m) incl += up;
+    }
+    const int L = __builtin_amdgcn_readlane(incl, 63);
+    const int R = 64 / a.k;
+    const int r = lane / a.k, e = lane - r * a.k;
+    for (int base = 0; base < L; base += R) {
+        const int li = base + r;
+        int lo = 0, hi = 63;  // probe of list li = first lane whose inclusive count exceeds li
+#pragma unroll
+        for (int step = 0; step < 6; ++step) {
+            const int mid = (lo + hi) >> 1;
+            if (__shfl(incl, mid) > li) hi = mid; else lo = mid + 1;
         }
+        const int p = lo > 63 ? 63 : lo;
+        const int si = li - (__shfl(incl, p) - __shfl(ns_l, p));
+        const long long t = (long long)(((unsigned long long)(unsigned)__shfl((int)(t0_l >> 32), p) << 32) | (unsigned)__shfl((int)t0_l, p)) +
+                            (long long)si * __shfl(ng_l, p);
+        const int j = __shfl(j_l, p);
+        uint64_t key = KEY_NONE;
+        // t >= max_tasks: table overflow, status[1] was set by the scan kernel and the caller repeats the call
+        if (r < R && li < L && t < a.max_tasks) key = a.partial[(t * a.QB + j) * a.k + e];
+        topk_offer(top, tau, key, a.k, lane);
     }
     store_topk(a.out_dist, a.out_idx, a.out_keys, q, a.k, top, lane);
 }
@@ -608,13 +625,13 @@ constexpr int TILED_QB = NLSH_TILED_QB;  // queries per task of the tiled schedu
 constexpr int TILED_TPS = NLSH_TILED_TPS;  // 64-row tiles per task of the tiled schedule (segment = 64*TPS rows)
 
 struct BWs {
-    size_t pbkt, pairpos, inv_q, bcount, pairoff, taskoff, bgroups, counters, btot, task, partial, qpad, tauq, total;
+    size_t pbkt, prec, inv_q, bcount, pairoff, taskoff, bgroups, counters, btot, task, partial, qpad, tauq, total;
 };
 static void blayout(long long Q, int P, int k, long long max_tasks, long long nb, int d, bool tiled, BWs *w) {
     size_t o = 0;
     const size_t qp = (size_t)Q * P * 4, nb4 = (size_t)(nb > 0 ? nb : 1) * 4;
     w->pbkt = o;     o += ws_align(qp);
-    w->pairpos = o;  o += ws_align(qp);
+    w->prec = o;     o += ws_align(qp * 4);
     w->inv_q = o;    o += ws_align(qp);
     w->bcount = o;   o += ws_align(nb4);
     w->pairoff = o;  o += ws_align(nb4);
@@ -660,7 +677,7 @@ int bucket_scan_run(const BucketScanCall &c) {
     if (c.tiled && !prep) { a.qpad = c.queries; a.qpad_stride = c.q_stride; }
     a.out_dist = c.out_dist; a.out_idx = c.out_idx; a.out_keys = c.out_keys; a.out_ncand = c.out_ncand; a.status = c.status;
     char *base = (char *)c.workspace;
-    a.pbkt = (int32_t *)(base + w.pbkt); a.pairpos = (int32_t *)(base + w.pairpos); a.inv_q = (int32_t *)(base + w.inv_q);
+    a.pbkt = (int32_t *)(base + w.pbkt); a.prec = (int4 *)(base + w.prec); a.inv_q = (int32_t *)(base + w.inv_q);
     a.bcount = (int32_t *)(base + w.bcount); a.pairoff = (int32_t *)(base + w.pairoff); a.taskoff = (int32_t *)(base + w.taskoff); a.bgroups = (int32_t *)(base + w.bgroups);
     a.counters = (int32_t *)(base + w.counters); a.btot = (int32_t *)(base + w.btot); a.border = c.bucket_order; a.task = (int4 *)(base + w.task); a.partial = (uint64_t *)(base + w.partial);
     a.max_tasks = c.max_tasks;
