@@ -299,6 +299,16 @@ def main():
         dist.destroy_process_group()
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args, corpus_h, queries_h, Ws, bs, indexer, hashing, queries, steps, metric):
     """CPU oracle (oracle/: C + OpenMP scan, BLAS forward) on a bounded sample of the same workload:
     same queries, same multi-probe keys (so identical candidate sets), same k."""
@@ -334,7 +344,7 @@ def cpu_baseline(args, corpus_h, queries_h, Ws, bs, indexer, hashing, queries, s
     out = {"value": sample * passes / (th + ts), "unit": "queries/s", "cores": threads, "kind": "port",
            "sample": f"first {sample} of {Q} queries x {passes} passes, same keys/candidate sets as the GPU run; "
                      f"hash {th:.3f}s (numpy BLAS) + scan {ts:.3f}s (C, OpenMP x{threads})",
-           "host_cpu_count": os.cpu_count()}
+           "host_cpu_count": os.cpu_count(), "host_cpu_model": _cpu_model()}
     # the same restatement on ONE thread (the reference's per-query loop is single-threaded Python over torch ops)
     oracle.set_num_threads(1)
     try:
