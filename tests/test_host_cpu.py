@@ -116,3 +116,24 @@ def test_synthetic_generators_are_deterministic():
     assert np.allclose(np.linalg.norm(synth.deep_like(10, 96), axis=1), 1.0, atol=1e-5)
     Ws, bs = synth.make_weights([128, 256, 16], seed=0)
     assert Ws[0].shape == (256, 128) and bs[1].shape == (16,)
+
+
+def test_reference_import_paths_resolve_to_the_hip_package():
+    """compat/ mirrors the reference's module paths, so `from nlsh.indexer import Indexer` needs no edit."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from nlsh.indexer import Indexer, build_index\n"
+        "from nlsh.hashings import MultivariateBernoulli\n"
+        "from nlsh.utils import hash_codes\n"
+        "from nlsh.metrics import calculate_recall\n"
+        "from nlsh.data import SIFT, Glove\n"
+        "from encoders import MultiLayerRelu, TwoLayer256Relu\n"
+        "import nlsh_amd.indexer, nlsh_amd.hashings, nlsh_amd.encoders\n"
+        "assert Indexer is nlsh_amd.indexer.Indexer and MultivariateBernoulli is nlsh_amd.hashings.MultivariateBernoulli\n"
+        "assert MultiLayerRelu is nlsh_amd.encoders.MultiLayerRelu\n"
+        "assert build_index([{3}, {5}, {3}], cuda=False)[3].tolist() == [0, 2]\n"
+        "print('ok')\n") % os.path.join(ROOT, "neural-locality-sensitive-hashing_amd", "compat")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-2000:]
