@@ -7,8 +7,12 @@
 A "step" = one pass of the hot path over the whole query batch (BASELINE.json configs[1]:
 SIFT1M-shaped, 1M x 128-d corpus, 10k queries, 16-bit hash, k=10, hash_times=10):
 encode_hash (MLP on fp32 MFMA + bits + multi-probe keys) -> plan -> scan_topk -> merge, all
-device-resident (inputs in HBM before the timed region, results left in HBM).  N>1: corpus rows
-buckets sharded over the ranks (whole buckets per rank, one build-time all-to-all; `--shard rows` keeps
+device-resident (inputs in HBM before the timed region, results left in HBM).  At N=1 every kernel of a step runs
+back to back on one stream; at N>1 the K timed steps run as a two-stage pipeline over two HIP streams
+(nlsh_amd/pipeline.py): encode + plan of batch i+1 on the front stream under scan + merge + all-gather of batch i on
+the back stream -- every kernel of every step still runs inside the timed region, scan kernels never overlap each
+other (`--pipeline on|off` forces either).
+N>1: corpus buckets sharded over the ranks (whole buckets per rank, one build-time all-to-all; `--shard rows` keeps
 contiguous row ranges instead), every rank answers all queries over its shard, one all-gather (RCCL) of
 the per-rank top-k + merge per step ("strong" scaling: total work fixed).
 
@@ -53,10 +57,12 @@ def parse():
     ap.add_argument("--seg-rows", type=int, default=0)
     ap.add_argument("--shard", default="buckets", choices=["buckets", "rows"],
                     help="N>1 partition of the corpus: whole buckets per rank (default) or contiguous row ranges")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("NLSH_BENCH_STREAMS", 1)),
-                    help="HIP streams the steps are dealt to round-robin (2 = batch i+1's encode/plan overlaps batch i's scan)")
-    ap.add_argument("--pipelined", action="store_true",
-                    help="also time the K steps dealt to two HIP streams (reported as `pipelined`, never as `value`)")
+    ap.add_argument("--pipeline", default="auto", choices=["auto", "on", "off"],
+                    help="two-stage pipeline over two HIP streams: encode+plan of batch i+1 on a front stream under "
+                         "scan+merge(+all-gather) of batch i on a back stream.  auto = on for N>1 (hides the collective and "
+                         "the per-batch fixed kernels, -14 %% local step at 8 shards), off for N=1 (every kernel runs alone, "
+                         "so the roofline timings are undisturbed; the pipeline is worth ~5 %% there)")
+    ap.add_argument("--also-other", action="store_true", help="additionally time the K steps in the other mode (reported as `other_mode`)")
     ap.add_argument("--algo", default=None, choices=["query", "bucket", "tiled"], help="force a scan schedule (default: auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--random-init", action="store_true", help="ignore the learned-hash checkpoint")
@@ -156,15 +162,29 @@ def main():
                 ev_x[i][1].record()
         return dist_, idx_, nc_
 
-    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))] if args.streams > 1 else [torch.cuda.current_stream(dev)]
+    step(-1, check=True)  # sizes the segment table (may retry once); untimed
+    pipe, cur = None, [None]
 
-    def run_step(i, **kw):
-        with torch.cuda.stream(streams[i % len(streams)]):
-            return step(i, **kw)
+    def exchange(k64, nc):   # back stage of the pipeline on a sharded index: all-gather of per-shard top-k + merge
+        i = cur[0]
+        if i is not None:
+            ev_x[i][0].record()
+        out_ = gather_and_merge(k64, nc, k)
+        if i is not None:
+            ev_x[i][1].record()
+        return out_
 
-    for st in streams:           # sizes the segment table of every stream's workspace (may retry once); untimed
-        with torch.cuda.stream(st):
-            step(-1, check=True)
+    use_pipeline = args.pipeline == "on" or (args.pipeline == "auto" and world > 1)
+    if use_pipeline:
+        from nlsh_amd.pipeline import QueryPipeline
+        pipe = QueryPipeline(indexer, queries, k=k, hash_times=P, depth=2, exchange=exchange if world > 1 else None)
+
+    def run_step(i, events=None):
+        if pipe is None:
+            return step(i, events=events)
+        cur[0] = i if events is not None else None
+        return pipe.submit(queries, seed=1000 + i, events=events)[:3]
+
     for i in range(warmup):
         run_step(-2 - i)
     torch.cuda.synchronize()
@@ -174,35 +194,35 @@ def main():
     t0 = time.perf_counter()
     for i in range(steps):
         out = run_step(i, events=ev[i])
+    if pipe is not None:
+        pipe.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    n_tasks, overflow = (int(v) for v in indexer.last_status.cpu())
-    assert overflow == 0, "segment table overflow inside the timed region"
+    last_status = pipe.last_slot.status if pipe is not None else indexer.last_status
+    n_tasks, overflow = (int(v) for v in last_status.cpu())
+    assert overflow == 0 and not (pipe is not None and pipe.overflowed()), "segment table overflow inside the timed region"
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # the same K steps dealt round-robin to two HIP streams (own workspaces): batch i+1's encode/plan kernels and
-    # batch i's scan tail overlap.  Reported beside `value`, never as `value`: kernel durations overlap in this
-    # mode, so the roofline figures come from the single-stream region above.
-    pipelined = None
-    if args.pipelined and world == 1 and len(streams) == 1:
-        two = [torch.cuda.Stream(device=dev) for _ in range(2)]
-        for st in two:
-            with torch.cuda.stream(st):
-                step(-1, check=True)
+    other_mode = None
+    if args.also_other and world == 1:
+        from nlsh_amd.pipeline import QueryPipeline
+        alt = QueryPipeline(indexer, queries, k=k, hash_times=P, depth=2) if pipe is None else None
+        for i in range(warmup):
+            alt.submit(queries, seed=i) if alt is not None else step(i)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            with torch.cuda.stream(two[i % 2]):
-                step(i)
+            alt.submit(queries, seed=1000 + i) if alt is not None else step(i)
         torch.cuda.synchronize()
         el2 = time.perf_counter() - t0
-        pipelined = {"streams": 2, "value": Q * steps / el2, "unit": "queries/s", "ms_per_step": 1e3 * el2 / steps}
+        other_mode = {"mode": "pipeline" if alt is not None else "sequential", "value": Q * steps / el2, "unit": "queries/s",
+                      "ms_per_step": 1e3 * el2 / steps}
 
     scan_ms = [a.elapsed_time(b) for a, b in ev]
     scan_avg_ms = float(np.mean(scan_ms))
@@ -286,8 +306,10 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms,
                          "sum_candidates_per_launch": sum_c_local, "tasks_per_launch": n_tasks},
         }
-        if pipelined is not None:
-            result["pipelined"] = pipelined
+        result["config"]["step_driver"] = ("two-stage pipeline over two HIP streams (nlsh_amd/pipeline.py)" if pipe is not None
+                                           else "sequential: every kernel of a step back to back on one stream")
+        if other_mode is not None:
+            result["other_mode"] = other_mode
         if enc is not None:
             result["encoder"] = enc
             result["roofline"]["hbm_copy_measured_GBps"] = copy_gbps

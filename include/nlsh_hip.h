@@ -156,6 +156,22 @@ int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, int d, const 
                    int32_t *status, void *workspace, size_t workspace_bytes, int64_t max_tasks,
                    void *ev_scan_begin, void *ev_scan_end, nlsh_stream_t stream);
 
+/* The same call cut in two, for callers that pipeline batches over two streams: NLSH_PHASE_PLAN runs everything
+ * up to the scan kernel (bucket lookup, candidate counts, task table; touches out_ncand, status and the workspace),
+ * NLSH_PHASE_SCAN the scan kernel and the merge (reads what PLAN left in the workspace; writes out_dist / out_idx /
+ * out_keys).  Both take the identical argument list; SCAN must be ordered after PLAN (an event between the two
+ * streams), and a workspace belongs to one batch until its SCAN has finished.  phases = PLAN | SCAN is
+ * nlsh_scan_topk.  The plan of batch i+1 (latency-bound, small kernels) then overlaps the scan of batch i. */
+#define NLSH_PHASE_PLAN 1
+#define NLSH_PHASE_SCAN 2
+int nlsh_scan_topk_phase(const float *corpus_sorted, int64_t row_stride, int d, const int32_t *gid,
+                         const int32_t *uniq_keys, const int32_t *offsets, const int32_t *bucket_order, int32_t n_buckets,
+                         const float *inv_norm, const float *queries, int64_t q_stride, int64_t Q,
+                         const int32_t *qkeys, const int32_t *nkeys, int P, int k, int metric, int algo, int seg_rows,
+                         float *out_dist, int32_t *out_idx, uint64_t *out_keys, int32_t *out_ncand,
+                         int32_t *status, void *workspace, size_t workspace_bytes, int64_t max_tasks,
+                         void *ev_scan_begin, void *ev_scan_end, nlsh_stream_t stream, int phases);
+
 /* Merge G per-shard top-k lists per query (keys_in [dev] [G, Q, row_stride] u64, the first k of each
  * row as all-gathered from nlsh_scan_topk's out_keys) into the global top-k; same comparator, so the
  * result equals the single-GPU result.  Candidate counts are summed into out_ncand from ncand_in

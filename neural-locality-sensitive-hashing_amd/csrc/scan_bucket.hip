@@ -685,20 +685,24 @@ int bucket_scan_run(const BucketScanCall &c) {
     a.tauq = (unsigned long long *)(base + w.tauq);
 
     hipStream_t s = c.stream;
-    {
+    if (c.phases & NLSH_PHASE_PLAN) {
         long long n_init = c.Q > c.nb ? c.Q : c.nb;
         if (n_init < 4) n_init = 4;
         hipLaunchKernelGGL(binit_kernel, dim3((unsigned)((n_init + 255) / 256)), dim3(256), 0, s, a);
+        const unsigned gp = (unsigned)((c.Q * c.P + 255) / 256);
+        hipLaunchKernelGGL(bplan_kernel, dim3(gp), dim3(256), 0, s, a);
+        if (c.nb > 0) {
+            const unsigned gb = (unsigned)((c.nb + 255) / 256);
+            hipLaunchKernelGGL(bcount_kernel, dim3(gb), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(bscan_kernel, dim3(gb), dim3(256), 0, s, a);
+        }
+        hipLaunchKernelGGL(bscatter_kernel, dim3(gp), dim3(256), 0, s, a);
+        if (prep) hipLaunchKernelGGL(bprep_kernel, dim3((unsigned)c.Q), dim3(64), 0, s, a, c.metric);
     }
-    const unsigned gp = (unsigned)((c.Q * c.P + 255) / 256);
-    hipLaunchKernelGGL(bplan_kernel, dim3(gp), dim3(256), 0, s, a);
-    if (c.nb > 0) {
-        const unsigned gb = (unsigned)((c.nb + 255) / 256);
-        hipLaunchKernelGGL(bcount_kernel, dim3(gb), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(bscan_kernel, dim3(gb), dim3(256), 0, s, a);
+    if (!(c.phases & NLSH_PHASE_SCAN)) {
+        NLSH_CHECK_HIP(hipGetLastError());
+        return NLSH_OK;
     }
-    hipLaunchKernelGGL(bscatter_kernel, dim3(gp), dim3(256), 0, s, a);
-    if (prep) hipLaunchKernelGGL(bprep_kernel, dim3((unsigned)c.Q), dim3(64), 0, s, a, c.metric);
     if (c.max_tasks > 0) {
         if (c.ev_begin) NLSH_CHECK_HIP(hipEventRecord((hipEvent_t)c.ev_begin, s));
         if (c.tiled) {

@@ -214,6 +214,7 @@ struct BucketScanCall {
     int P, k, metric, seg; float *out_dist; int32_t *out_idx; uint64_t *out_keys; int32_t *out_ncand; int32_t *status;
     void *workspace; size_t workspace_bytes; long long max_tasks; void *ev_begin; void *ev_end; hipStream_t stream; int tiled;
     const int32_t *bucket_order;  // nlsh_bucket_order output or nullptr
+    int phases;                   // NLSH_PHASE_PLAN | NLSH_PHASE_SCAN
 };
 size_t bucket_scan_workspace(long long Q, int P, int k, long long max_tasks, long long n_buckets, int d);
 int bucket_scan_run(const BucketScanCall &c);

@@ -271,12 +271,13 @@ extern "C" size_t nlsh_scan_workspace(int64_t Q, int P, int k, int64_t max_tasks
     return w.total > b ? w.total : b;
 }
 
-extern "C" int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, int d, const int32_t *gid,
+extern "C" int nlsh_scan_topk_phase(const float *corpus_sorted, int64_t row_stride, int d, const int32_t *gid,
                               const int32_t *uniq_keys, const int32_t *offsets, const int32_t *bucket_order, int32_t n_buckets,
                               const float *inv_norm, const float *queries, int64_t q_stride, int64_t Q, const int32_t *qkeys, const int32_t *nkeys,
                               int P, int k, int metric, int algo, int seg_rows, float *out_dist, int32_t *out_idx,
                               uint64_t *out_keys, int32_t *out_ncand, int32_t *status, void *workspace, size_t workspace_bytes,
-                              int64_t max_tasks, void *ev_scan_begin, void *ev_scan_end, nlsh_stream_t stream) {
+                              int64_t max_tasks, void *ev_scan_begin, void *ev_scan_end, nlsh_stream_t stream, int phases) {
+    NLSH_REQUIRE(phases >= 1 && phases <= (NLSH_PHASE_PLAN | NLSH_PHASE_SCAN), NLSH_E_INVALID, "scan_topk: phases=%d", phases);
     NLSH_REQUIRE(Q >= 0 && Q < (1ll << 31), NLSH_E_INVALID, "scan_topk: Q=%lld", (long long)Q);
     NLSH_REQUIRE(d >= 1 && d <= NLSH_MAX_DIM, NLSH_E_UNSUPPORTED, "scan_topk: d=%d not in [1,%d]", d, NLSH_MAX_DIM);
     NLSH_REQUIRE(k >= 1 && k <= NLSH_MAX_K, NLSH_E_UNSUPPORTED, "scan_topk: k=%d not in [1,%d]", k, NLSH_MAX_K);
@@ -299,7 +300,7 @@ extern "C" int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, in
     if (algo != NLSH_SCAN_QUERY_MAJOR) {
         BucketScanCall c = {corpus_sorted, row_stride, d, gid, uniq_keys, offsets, n_buckets, inv_norm, queries, q_stride, Q,
                             qkeys, nkeys, P, k, metric, seg_rows, out_dist, out_idx, out_keys, out_ncand, status, workspace,
-                            workspace_bytes, max_tasks, ev_scan_begin, ev_scan_end, s, algo == NLSH_SCAN_BUCKET_TILED, bucket_order};
+                            workspace_bytes, max_tasks, ev_scan_begin, ev_scan_end, s, algo == NLSH_SCAN_BUCKET_TILED, bucket_order, phases};
         return bucket_scan_run(c);
     }
 
@@ -316,9 +317,11 @@ extern "C" int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, in
     a.tbase = (int32_t *)(base + w.tbase); a.task_q = (int32_t *)(base + w.task_q); a.task_s = (int32_t *)(base + w.task_s);
     a.partial = (uint64_t *)(base + w.partial);
 
-    NLSH_CHECK_HIP(hipMemsetAsync(status, 0, 2 * sizeof(int32_t), s));
-    hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s, a);
-    if (max_tasks > 0) {
+    if (phases & NLSH_PHASE_PLAN) {
+        NLSH_CHECK_HIP(hipMemsetAsync(status, 0, 2 * sizeof(int32_t), s));
+        hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s, a);
+    }
+    if ((phases & NLSH_PHASE_SCAN) && max_tasks > 0) {
         const unsigned grid = (unsigned)((max_tasks + 3) / 4);
         const int d4 = (d + 3) / 4;
         if (ev_scan_begin) NLSH_CHECK_HIP(hipEventRecord((hipEvent_t)ev_scan_begin, s));
@@ -329,6 +332,19 @@ extern "C" int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, in
     }
     NLSH_CHECK_HIP(hipGetLastError());
     return NLSH_OK;
+}
+
+extern "C" int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, int d, const int32_t *gid,
+                              const int32_t *uniq_keys, const int32_t *offsets, const int32_t *bucket_order, int32_t n_buckets,
+                              const float *inv_norm, const float *queries, int64_t q_stride, int64_t Q, const int32_t *qkeys,
+                              const int32_t *nkeys, int P, int k, int metric, int algo, int seg_rows, float *out_dist,
+                              int32_t *out_idx, uint64_t *out_keys, int32_t *out_ncand, int32_t *status, void *workspace,
+                              size_t workspace_bytes, int64_t max_tasks, void *ev_scan_begin, void *ev_scan_end,
+                              nlsh_stream_t stream) {
+    return nlsh_scan_topk_phase(corpus_sorted, row_stride, d, gid, uniq_keys, offsets, bucket_order, n_buckets, inv_norm, queries,
+                                q_stride, Q, qkeys, nkeys, P, k, metric, algo, seg_rows, out_dist, out_idx, out_keys, out_ncand,
+                                status, workspace, workspace_bytes, max_tasks, ev_scan_begin, ev_scan_end, stream,
+                                NLSH_PHASE_PLAN | NLSH_PHASE_SCAN);
 }
 
 extern "C" int nlsh_merge_topk(const uint64_t *keys_in, int64_t row_stride, int G, int64_t Q, int k, const int32_t *ncand_in,

@@ -17,6 +17,7 @@ KEY_REF_INT16, KEY_FULL = 0, 1
 METRIC_L2_EPS, METRIC_COSINE = 0, 1
 SCAN_QUERY_MAJOR, SCAN_BUCKET_MAJOR, SCAN_BUCKET_TILED = 0, 1, 2
 MAX_LAYERS, MAX_HASH_BITS, MAX_PROBES, MAX_K, MAX_DIM, MAX_WIDTH = 8, 32, 64, 64, 1024, 632
+PHASE_PLAN, PHASE_SCAN = 1, 2
 MAX_ENCODE_PROBES = 128  # nlsh_encode_hash generates up to this many keys per row; the scan takes them in slices of MAX_PROBES
 
 # every symbol include/nlsh_hip.h declares (tests/test_capi_symbols.py checks the header against this)
@@ -24,7 +25,7 @@ SYMBOLS = (
     "nlsh_abi_version", "nlsh_last_error",
     "nlsh_encoder_packed_floats", "nlsh_encoder_pack", "nlsh_encode_hash", "nlsh_pack_codes",
     "nlsh_build_csr_workspace", "nlsh_build_csr", "nlsh_bucket_order_workspace", "nlsh_bucket_order", "nlsh_gather_rows",
-    "nlsh_scan_workspace", "nlsh_scan_topk", "nlsh_merge_topk",
+    "nlsh_scan_workspace", "nlsh_scan_topk", "nlsh_scan_topk_phase", "nlsh_merge_topk",
 )
 
 
@@ -80,6 +81,8 @@ def lib():
     L.nlsh_scan_topk.restype = i32
     L.nlsh_scan_topk.argtypes = [vp, i64, i32, vp, vp, vp, vp, ctypes.c_int32, vp, vp, i64, i64, vp, vp, i32, i32, i32, i32, i32,
                                  vp, vp, vp, vp, vp, vp, sz, i64, vp, vp, vp]
+    L.nlsh_scan_topk_phase.restype = i32
+    L.nlsh_scan_topk_phase.argtypes = list(L.nlsh_scan_topk.argtypes) + [i32]
     L.nlsh_merge_topk.restype = i32
     L.nlsh_merge_topk.argtypes = [vp, i64, i32, i64, i32, vp, vp, vp, vp, vp]
     _lib = L

@@ -90,7 +90,7 @@ class MultivariateBernoulli:
         return keys_to_sets(keys, nkeys, self.key_mode)
 
     # ------------------------------------------------------------------ device-resident form
-    def hash_device(self, x, n=1, n_multi_rows=None, seed=None, row0=0):
+    def hash_device(self, x, n=1, n_multi_rows=None, seed=None, row0=0, out=None):
         """-> (keys int32 [B, n] distinct, first-occurrence order; nkeys int32 [B]) on the device.
 
         Rows >= n_multi_rows are single-probe (Indexer.hash's trailing-batch rule).  `seed`
@@ -98,7 +98,7 @@ class MultivariateBernoulli:
         """
         if n < 1:
             raise ValueError(f"`n` should be positive integer, but got {n}")
-        keys, nkeys, _ = self._run(x, n, n_multi_rows=n_multi_rows, seed=seed, row0=row0)
+        keys, nkeys, _ = self._run(x, n, n_multi_rows=n_multi_rows, seed=seed, row0=row0, out=out)
         return keys, nkeys
 
     def forward_device(self, x):
@@ -147,7 +147,7 @@ class MultivariateBernoulli:
         self._packed, self._packed_sig, self._keep = packed, sig, stack
         return packed
 
-    def _run(self, x, n, n_multi_rows=None, seed=None, row0=0, want_probs=False, z_out=None, code_out=None):
+    def _run(self, x, n, n_multi_rows=None, seed=None, row0=0, want_probs=False, z_out=None, code_out=None, out=None):
         if x.device.type != "cuda":
             raise _capi.NlshHipError(_capi.E_INVALID, "encode_hash needs a device tensor; there is no CPU path")
         if n > _capi.MAX_ENCODE_PROBES:
@@ -163,8 +163,13 @@ class MultivariateBernoulli:
             raise ValueError(f"input dim {x.shape[1]} != encoder input dim {dims[0]}")
         B = x.shape[0]
         packed = self.packed_weights()
-        keys = torch.empty((B, n), dtype=torch.int32, device=x.device)
-        nkeys = torch.empty((B,), dtype=torch.int32, device=x.device)
+        if out is not None:   # caller-owned key table (pipelined batches keep theirs across streams)
+            keys, nkeys = out
+            if keys.shape != (B, n) or keys.dtype != torch.int32 or nkeys.shape != (B,) or nkeys.dtype != torch.int32:
+                raise ValueError("out must be (int32 [B, n], int32 [B])")
+        else:
+            keys = torch.empty((B, n), dtype=torch.int32, device=x.device)
+            nkeys = torch.empty((B,), dtype=torch.int32, device=x.device)
         probs = torch.empty((B, self._hash_size), dtype=torch.float32, device=x.device) if want_probs else None
         if seed is None:
             seed = (self._seed + 0x9E3779B97F4A7C15 * (next(self._calls) + 1)) & 0xFFFFFFFFFFFFFFFF

@@ -173,9 +173,9 @@ class Indexer:
         # indexer.py:43-53: only full batches get hash_times; the trailing partial batch is n=1 (F6)
         return (n // batch_size) * batch_size if self.compat else n
 
-    def hash_device(self, query_vectors, batch_size=HASH_BATCH, hash_times=1, seed=None):
+    def hash_device(self, query_vectors, batch_size=HASH_BATCH, hash_times=1, seed=None, out=None):
         return self._hashing.hash_device(query_vectors, n=hash_times,
-                                         n_multi_rows=self._n_multi_rows(query_vectors.shape[0], batch_size), seed=seed)
+                                         n_multi_rows=self._n_multi_rows(query_vectors.shape[0], batch_size), seed=seed, out=out)
 
     def hash(self, query_vectors, batch_size=HASH_BATCH, hash_times=1) -> List[Set[int]]:
         keys, nkeys = self.hash_device(query_vectors, batch_size, hash_times)
@@ -253,12 +253,8 @@ class Indexer:
             ws = self._ws.get(stream)
             if ws is None or ws.numel() < ws_bytes or ws.device != dev:
                 ws = self._ws[stream] = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
-            _capi.check(L.nlsh_scan_topk(
-                _capi.ptr(self.corpus_sorted), self.row_stride, d, _capi.ptr(self.gid), _capi.ptr(self.uniq_keys),
-                _capi.ptr(self.offsets), _capi.ptr(self.bucket_order), self.n_buckets, _capi.ptr(self.inv_norm), _capi.ptr(q), q.stride(0) if Q else d, Q,
-                _capi.ptr(keys), _capi.ptr(nkeys), P, k, metric, algo, seg, _capi.ptr(out_dist), _capi.ptr(out_idx),
-                _capi.ptr(out_keys), _capi.ptr(ncand), _capi.ptr(status), _capi.ptr(ws), ws.numel(), max_tasks,
-                events[0].cuda_event if events else None, events[1].cuda_event if events else None, stream))
+            self._scan_launch(q, keys, nkeys, k, algo, max_tasks, out_dist, out_idx, out_keys, ncand, status, ws,
+                              _capi.PHASE_PLAN | _capi.PHASE_SCAN, events)
             if not check or Q == 0:
                 break
             needed, overflow = status.cpu().tolist()
@@ -268,6 +264,18 @@ class Indexer:
         self.last_status = status
         self.last_algo = algo
         return out_dist, out_idx, ncand, out_keys
+
+    def _scan_launch(self, q, keys, nkeys, k, algo, max_tasks, out_dist, out_idx, out_keys, ncand, status, ws, phases, events=None):
+        """One `nlsh_scan_topk_phase` call on the current stream with caller-owned buffers (PLAN, SCAN or both)."""
+        Q, d = q.shape
+        metric = _capi.METRIC_L2_EPS if self.metric == "l2" else _capi.METRIC_COSINE
+        _capi.check(_capi.lib().nlsh_scan_topk_phase(
+            _capi.ptr(self.corpus_sorted), self.row_stride, d, _capi.ptr(self.gid), _capi.ptr(self.uniq_keys),
+            _capi.ptr(self.offsets), _capi.ptr(self.bucket_order), self.n_buckets, _capi.ptr(self.inv_norm), _capi.ptr(q),
+            q.stride(0) if Q else d, Q, _capi.ptr(keys), _capi.ptr(nkeys), keys.shape[1], k, metric, algo, self.seg_rows or 512,
+            _capi.ptr(out_dist), _capi.ptr(out_idx), _capi.ptr(out_keys), _capi.ptr(ncand), _capi.ptr(status), _capi.ptr(ws),
+            ws.numel(), max_tasks, events[0].cuda_event if events else None, events[1].cuda_event if events else None,
+            _stream(q.device), phases))
 
     def _scan_sliced(self, q, keys, nkeys, k, want_keys, check):
         """hash_times > 64 (eval.py:148 sweeps n_samples up to 100): the key table is scanned in column slices of

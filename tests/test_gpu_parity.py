@@ -469,3 +469,36 @@ def test_save_then_load_checkpoint_roundtrip(tmp_path):
     h3.train_mode(False)
     k2, _ = h3.hash_device(dev(x), n=4, seed=9)
     assert torch.equal(k0, k2)
+
+
+def test_pipelined_batches_are_bit_identical_to_sequential_calls():
+    """nlsh_amd/pipeline.py: front stream encode + PLAN, back stream SCAN -- same kernels, same arguments."""
+    from nlsh_amd.data import Glove, SIFT
+    from nlsh_amd.indexer import Indexer
+    from nlsh_amd.pipeline import QueryPipeline
+    for metric, d, fn, algo in (("l2", 128, SIFT.distance, "tiled"), ("cosine", 100, Glove.distance, "query"), ("l2", 64, SIFT.distance, "bucket")):
+        gen = synth.sift_like if metric == "l2" else synth.glove_like
+        N, Q, H, k, P = 40000, 512, 9, 10, 8
+        corpus = gen(N, d, seed=41)
+        Ws, bs = synth.make_weights([d, 64, H], seed=41)
+        hashing = make_hashing(d, (64,), H, Ws, bs, compat=False)
+        indexer = Indexer(hashing, dev(corpus), fn, compat=False, algo=algo)
+        batches = [dev(gen(Q, d, seed=50 + i)) for i in range(5)]
+        want = [indexer.query_tensors(b, k=k, hash_times=P, seed=900 + i, want_keys=True) for i, b in enumerate(batches)]
+        want = [tuple(t.clone() for t in w) for w in want]
+        pipe = QueryPipeline(indexer, batches[0], k=k, hash_times=P, depth=2, want_keys=True)
+        got = []
+        for i, b in enumerate(batches):
+            out = pipe.submit(b, seed=900 + i)
+            if i >= 1:                       # a slot is overwritten `depth` submits later: read batch i-1 now
+                pipe.back.wait_event(pipe.slots[(i - 1) % 2].done)
+            got.append(out)
+            if i % 2 == 1:
+                pipe.synchronize()
+                for j in (i - 1, i):
+                    for a, w in zip(got[j], want[j]):
+                        assert torch.equal(a, w), (metric, algo, j)
+        pipe.synchronize()
+        for a, w in zip(got[4], want[4]):
+            assert torch.equal(a, w)
+        assert not pipe.overflowed()

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--q", type=int, default=10_000)
     ap.add_argument("--shard", default="buckets", choices=["buckets", "rows"])
+    ap.add_argument("--pipeline", action="store_true", help="two-stage pipeline over two streams (nlsh_amd/pipeline.py)")
     args = ap.parse_args()
     from nlsh_amd import io, synth
     from nlsh_amd.data import SIFT
@@ -57,12 +58,22 @@ def main():
     for i in range(3):
         indexer.query_tensors(queries, k=10, hash_times=10, seed=2 + i, want_keys=True, check=False)
     torch.cuda.synchronize()
+    pipe = None
+    if args.pipeline:
+        from nlsh_amd.pipeline import QueryPipeline
+        pipe = QueryPipeline(indexer, queries, k=10, hash_times=10, depth=2, want_keys=True)
+        for i in range(3):
+            pipe.submit(queries, seed=50 + i)
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        indexer.query_tensors(queries, k=10, hash_times=10, seed=100 + i, want_keys=True, check=False, events=ev[i])
+        if pipe is not None:
+            pipe.submit(queries, seed=100 + i, events=ev[i])
+        else:
+            indexer.query_tensors(queries, k=10, hash_times=10, seed=100 + i, want_keys=True, check=False, events=ev[i])
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    print(json.dumps({"world": args.world, "rank": args.rank, "shard": args.shard, "rows": hi - lo, "algo": indexer.last_algo,
+    print(json.dumps({"world": args.world, "rank": args.rank, "shard": args.shard, "pipeline": bool(args.pipeline), "rows": hi - lo, "algo": indexer.last_algo,
                       "local_step_ms": 1e3 * el / args.steps, "scan_ms": float(np.mean([a.elapsed_time(b) for a, b in ev]))}))
 
 
