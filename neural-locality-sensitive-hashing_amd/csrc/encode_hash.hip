@@ -69,6 +69,11 @@ __device__ __forceinline__ void philox4x32_10(unsigned long long seed, uint32_t 
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// Batches up to this many rows take the single-image 32-row form (2 x 256 CUs x 32 rows: every workgroup resident at once)
+#ifndef NLSH_ENC_SINGLE_MAX_ROWS
+#define NLSH_ENC_SINGLE_MAX_ROWS 16384
+#endif
+
 // Diagnostic build only (make EXTRA=-DNLSH_ENC_TRACE, tools/enc_trace.py): thread 0 of every workgroup
 // leaves the 100 MHz wall_clock64 stamp of each phase boundary in the first floats of its z_out rows.
 #ifdef NLSH_ENC_TRACE
@@ -77,7 +82,12 @@ __device__ __forceinline__ void philox4x32_10(unsigned long long seed, uint32_t 
 #define ENC_STAMP(i) do { } while (0)
 #endif
 
-template <int RT, int NW>
+// SINGLE: one LDS image instead of the ping-pong pair.  A wave keeps the accumulators of ALL its column tiles
+// (<= MT) in registers until every wave has finished reading the layer's input, then the outputs overwrite the image.
+// With RT = 1 that is 33 KB at width 256 -- small enough to sit on a CU BESIDE six resident workgroups of the scan
+// kernel (20 KB each), which is what lets the batch pipeline (nlsh_amd/pipeline.py) run a query batch's encode under
+// the previous batch's scan; the 133 KB ping-pong form only finds a CU once the scan's dispatch queue has drained.
+template <int RT, int NW, bool SINGLE, int MT = 1>  // MT: column tiles a wave may own in SINGLE mode (1: width <= 32*NW)
 __global__ __launch_bounds__(NW * 64) void encode_hash_kernel(EncArgs a) {
     constexpr int M = 32 * RT;
     constexpr int NTH = NW * 64;
@@ -85,7 +95,7 @@ __global__ __launch_bounds__(NW * 64) void encode_hash_kernel(EncArgs a) {
     float *smem = reinterpret_cast<float *>(smem4);
     const int S = a.S;
     float *in = smem;
-    float *out = smem + (size_t)M * S;
+    float *out = SINGLE ? smem : smem + (size_t)M * S;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -148,8 +158,27 @@ __global__ __launch_bounds__(NW * 64) void encode_hash_kernel(EncArgs a) {
         if (!last) {
             const int NT = L.Np >> 5;
             const int ncol_keep = a.L[l + 1].Kp;  // columns the next layer reads (>= N, zero padded)
-            for (int nt0 = wave; nt0 < NT; nt0 += NW) {
-                f32x16 acc[RT];
+            f32x16 accs[MT][RT];
+            auto write_back = [&](int nt0, const f32x16 (&acc)[RT]) {
+                // bias + ReLU (encoders.py:19-20), C/D map: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
+                const int col = nt0 * 32 + lr;
+                if (col < ncol_keep) {
+                    const float bias = Bp[col];
+                    const int pc = pos(col);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int row = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+                            float v = acc[rt][i] + bias;
+                            out[(size_t)row * S + pc] = v > 0.0f ? v : 0.0f;
+                        }
+                }
+            };
+#pragma unroll
+            for (int m = 0; m < (SINGLE ? MT : 1); ++m)
+            for (int nt0 = wave + m * NW; nt0 < (SINGLE ? min(NT, wave + m * NW + 1) : NT); nt0 += NW) {
+                f32x16 (&acc)[RT] = accs[m];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -214,24 +243,16 @@ __global__ __launch_bounds__(NW * 64) void encode_hash_kernel(EncArgs a) {
                         }
                     }
                 }
-                // write-back: bias + ReLU (encoders.py:19-20), C/D map: col = lane&31,
-                // row = (i&3) + 8*(i>>2) + 4*(lane>>5)
-                const int col = nt0 * 32 + lr;
-                if (col < ncol_keep) {
-                    const float bias = Bp[col];
-                    const int pc = pos(col);
+                if (!SINGLE) write_back(nt0, acc);
+            }
+            if (SINGLE) {
+                __syncthreads();  // every wave has finished reading this layer's input: the image may be overwritten
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const int row = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-                            float v = acc[rt][i] + bias;
-                            out[(size_t)row * S + pc] = v > 0.0f ? v : 0.0f;
-                        }
-                }
+                for (int m = 0; m < MT; ++m)
+                    if (wave + m * NW < NT) write_back(wave + m * NW, accs[m]);
             }
             __syncthreads();
-            float *t = in; in = out; out = t;
+            if (!SINGLE) { float *t = in; in = out; out = t; }
             ENC_STAMP(2 + (l < 4 ? l : 4));
         } else {
             // output layer: H <= 32 -> one column tile; one row tile per wavefront
@@ -288,7 +309,7 @@ __global__ __launch_bounds__(NW * 64) void encode_hash_kernel(EncArgs a) {
     // ---- epilogue.  `out` holds z [M][33]; `in` is free.
     const int H = a.H;
     float *zbuf = out;
-    float *pbuf = in;  // Bernoulli probability [M][33]
+    float *pbuf = SINGLE ? smem + M * 33 : in;  // Bernoulli probability [M][33]
     for (int e = tid; e < M * H; e += NTH) {
         int r = e / H, h = e - r * H;
         long long grow = row_base + r;
@@ -309,7 +330,8 @@ __global__ __launch_bounds__(NW * 64) void encode_hash_kernel(EncArgs a) {
     }
     __syncthreads();
     ENC_STAMP(8);
-    int32_t *kbuf = reinterpret_cast<int32_t *>(out);  // [M][n_probes]; z is dead now
+    // [M][n_probes] key table: over z (dead now) in the ping-pong form, behind z and p in the single image
+    int32_t *kbuf = reinterpret_cast<int32_t *>(SINGLE ? smem + 2 * M * 33 : out);
     const int NP = a.n_probes;
     for (int e = tid; e < M * NP; e += NTH) {
         int r = e / NP, j = e - r * NP;
@@ -489,18 +511,28 @@ extern "C" int nlsh_encode_hash(const float *x, int64_t n, int64_t x_stride, int
 
     hipStream_t s = (hipStream_t)stream;
     const size_t lds_limit = 160 * 1024;
-    // (32-row workgroups for query-sized batches, two per CU, measured the same step time twice: 0.455 vs 0.451 ms)
-    if ((size_t)2 * 64 * a.S * 4 <= lds_limit) {
-        size_t lds = (size_t)2 * 64 * a.S * 4;
-        NLSH_CHECK_HIP(hipFuncSetAttribute((const void *)encode_hash_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        long long grid = (n + 63) / 64;
-        hipLaunchKernelGGL((encode_hash_kernel<2, 8>), dim3((unsigned)grid), dim3(512), lds, s, a);
-    } else {
-        size_t lds = (size_t)2 * 32 * a.S * 4;
+    // Query-sized batches (and encoders too wide for two 64-row images) run 32-row workgroups on a SINGLE LDS image;
+    // its rows must also hold the epilogue's z, p and key tables side by side (66 + n_probes floats per row).
+    const bool single = n <= NLSH_ENC_SINGLE_MAX_ROWS || (size_t)2 * 64 * a.S * 4 > lds_limit;
+    if (single) {
+        if (72 + round_up(n_probes, 8) > maxKp) a.S = 72 + round_up(n_probes, 8) + 4;
+        size_t lds = (size_t)32 * a.S * 4;
         NLSH_REQUIRE(lds <= lds_limit, NLSH_E_UNSUPPORTED, "encode_hash: width %d needs %zu B of LDS", maxKp, lds);
-        NLSH_CHECK_HIP(hipFuncSetAttribute((const void *)encode_hash_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         long long grid = (n + 31) / 32;
-        hipLaunchKernelGGL((encode_hash_kernel<1, 8>), dim3((unsigned)grid), dim3(512), lds, s, a);
+        int max_np = 0;  // widest hidden layer decides how many column tiles a wave owns
+        for (int l = 0; l + 1 < n_layers; ++l) if (a.L[l].Np > max_np) max_np = a.L[l].Np;
+        if (max_np <= 32 * 8) {
+            NLSH_CHECK_HIP(hipFuncSetAttribute((const void *)encode_hash_kernel<1, 8, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((encode_hash_kernel<1, 8, true, 1>), dim3((unsigned)grid), dim3(512), lds, s, a);
+        } else {
+            NLSH_CHECK_HIP(hipFuncSetAttribute((const void *)encode_hash_kernel<1, 8, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((encode_hash_kernel<1, 8, true, 3>), dim3((unsigned)grid), dim3(512), lds, s, a);
+        }
+    } else {
+        size_t lds = (size_t)2 * 64 * a.S * 4;
+        NLSH_CHECK_HIP(hipFuncSetAttribute((const void *)encode_hash_kernel<2, 8, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        long long grid = (n + 63) / 64;
+        hipLaunchKernelGGL((encode_hash_kernel<2, 8, false, 1>), dim3((unsigned)grid), dim3(512), lds, s, a);
     }
     NLSH_CHECK_HIP(hipGetLastError());
     return NLSH_OK;

@@ -45,7 +45,8 @@ class QueryPipeline:
         self.algo = indexer.last_algo
         self.max_tasks = indexer._max_tasks[self.algo]
         ws_bytes = _capi.lib().nlsh_scan_workspace(self.Q, self.P, k, self.max_tasks, indexer.n_buckets, self.d)
-        self.front, self.back = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        # the front stage is many small workgroups that must slip in beside the scan: give its queue the higher priority
+        self.front, self.back = torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev, priority=0)
         self.slots = []
         for _ in range(depth):
             s = _Slot()
