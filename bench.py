@@ -7,10 +7,10 @@
 A "step" = one pass of the hot path over the whole query batch (BASELINE.json configs[1]:
 SIFT1M-shaped, 1M x 128-d corpus, 10k queries, 16-bit hash, k=10, hash_times=10):
 encode_hash (MLP on fp32 MFMA + bits + multi-probe keys) -> plan -> scan_topk -> merge, all
-device-resident (inputs in HBM before the timed region, results left in HBM).  The K timed steps run as a two-stage
-pipeline over two HIP streams (nlsh_amd/pipeline.py): encode + plan of batch i+1 on the front stream under scan +
-merge (+ all-gather at N>1) of batch i on the back stream -- every kernel of every step runs inside the timed
-region, scan kernels never overlap each other, results are bit-identical to sequential calls.  `--pipeline off`
+device-resident (inputs in HBM before the timed region, results left in HBM).  The K timed steps run as a
+three-stage pipeline over three HIP streams (nlsh_amd/pipeline.py): encode + plan of batch i+1 and merge (+ all-gather
+at N>1) of batch i-1 beside the scan of batch i -- every kernel of every step runs inside the timed region, scan
+kernels never overlap each other, results are bit-identical to sequential calls.  `--pipeline off`
 runs every kernel of a step back to back on one stream.
 N>1: corpus buckets sharded over the ranks (whole buckets per rank, one build-time all-to-all; `--shard rows` keeps
 contiguous row ranges instead), every rank answers all queries over its shard, one all-gather (RCCL) of
@@ -58,10 +58,9 @@ def parse():
     ap.add_argument("--shard", default="buckets", choices=["buckets", "rows"],
                     help="N>1 partition of the corpus: whole buckets per rank (default) or contiguous row ranges")
     ap.add_argument("--pipeline", default="on", choices=["on", "off"],
-                    help="on: two-stage pipeline over two HIP streams, encode+plan of batch i+1 on a (high-priority) front "
-                         "stream under scan+merge(+all-gather) of batch i on a back stream (-9 %% step time at N=1, -20 %% "
-                         "local step at 8 shards, and it hides the collective).  off: every kernel of a step back to back on "
-                         "one stream (each kernel alone on the chip)")
+                    help="on: three-stage pipeline over three HIP streams, encode+plan of batch i+1 and merge(+all-gather) of "
+                         "batch i-1 on high-priority streams beside the scan of batch i.  off: every kernel of a step back "
+                         "to back on one stream (each kernel alone on the chip)")
     ap.add_argument("--also-other", action="store_true", help="additionally time the K steps in the other mode (reported as `other_mode`)")
     ap.add_argument("--algo", default=None, choices=["query", "bucket", "tiled"], help="force a scan schedule (default: auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -177,7 +176,7 @@ def main():
     use_pipeline = args.pipeline == "on"
     if use_pipeline:
         from nlsh_amd.pipeline import QueryPipeline
-        pipe = QueryPipeline(indexer, queries, k=k, hash_times=P, depth=2, exchange=exchange if world > 1 else None)
+        pipe = QueryPipeline(indexer, queries, k=k, hash_times=P, depth=3, exchange=exchange if world > 1 else None)
 
     def run_step(i, events=None):
         if pipe is None:
@@ -212,7 +211,7 @@ def main():
     other_mode = None
     if args.also_other and world == 1:
         from nlsh_amd.pipeline import QueryPipeline
-        alt = QueryPipeline(indexer, queries, k=k, hash_times=P, depth=2) if pipe is None else None
+        alt = QueryPipeline(indexer, queries, k=k, hash_times=P, depth=3) if pipe is None else None
         for i in range(warmup):
             alt.submit(queries, seed=i) if alt is not None else step(i)
         torch.cuda.synchronize()
@@ -306,7 +305,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms,
                          "sum_candidates_per_launch": sum_c_local, "tasks_per_launch": n_tasks},
         }
-        result["config"]["step_driver"] = ("two-stage pipeline over two HIP streams (nlsh_amd/pipeline.py)" if pipe is not None
+        result["config"]["step_driver"] = ("three-stage pipeline over three HIP streams (nlsh_amd/pipeline.py)" if pipe is not None
                                            else "sequential: every kernel of a step back to back on one stream")
         if other_mode is not None:
             result["other_mode"] = other_mode

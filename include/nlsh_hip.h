@@ -156,14 +156,17 @@ int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, int d, const 
                    int32_t *status, void *workspace, size_t workspace_bytes, int64_t max_tasks,
                    void *ev_scan_begin, void *ev_scan_end, nlsh_stream_t stream);
 
-/* The same call cut in two, for callers that pipeline batches over two streams: NLSH_PHASE_PLAN runs everything
- * up to the scan kernel (bucket lookup, candidate counts, task table; touches out_ncand, status and the workspace),
- * NLSH_PHASE_SCAN the scan kernel and the merge (reads what PLAN left in the workspace; writes out_dist / out_idx /
- * out_keys).  Both take the identical argument list; SCAN must be ordered after PLAN (an event between the two
- * streams), and a workspace belongs to one batch until its SCAN has finished.  phases = PLAN | SCAN is
- * nlsh_scan_topk.  The plan of batch i+1 (latency-bound, small kernels) then overlaps the scan of batch i. */
+/* The same call cut in three, for callers that pipeline batches over streams: NLSH_PHASE_PLAN runs everything up
+ * to the scan kernel (bucket lookup, candidate counts, task table; touches out_ncand, status and the workspace),
+ * NLSH_PHASE_SCAN the scan kernel (reads what PLAN left in the workspace, leaves per-task partial top-k lists there),
+ * NLSH_PHASE_MERGE the per-query merge of those lists (writes out_dist / out_idx / out_keys).  All take the identical
+ * argument list and may be combined; each must be ordered after the previous one (an event when they run on
+ * different streams), and a workspace belongs to one batch until its MERGE has finished.  All three bits =
+ * nlsh_scan_topk.  The plan of batch i+1 and the merge of batch i-1 (latency-bound, small kernels) then overlap the
+ * scan of batch i (nlsh_amd/pipeline.py). */
 #define NLSH_PHASE_PLAN 1
 #define NLSH_PHASE_SCAN 2
+#define NLSH_PHASE_MERGE 4
 int nlsh_scan_topk_phase(const float *corpus_sorted, int64_t row_stride, int d, const int32_t *gid,
                          const int32_t *uniq_keys, const int32_t *offsets, const int32_t *bucket_order, int32_t n_buckets,
                          const float *inv_norm, const float *queries, int64_t q_stride, int64_t Q,

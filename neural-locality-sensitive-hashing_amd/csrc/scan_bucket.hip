@@ -699,11 +699,7 @@ int bucket_scan_run(const BucketScanCall &c) {
         hipLaunchKernelGGL(bscatter_kernel, dim3(gp), dim3(256), 0, s, a);
         if (prep) hipLaunchKernelGGL(bprep_kernel, dim3((unsigned)c.Q), dim3(64), 0, s, a, c.metric);
     }
-    if (!(c.phases & NLSH_PHASE_SCAN)) {
-        NLSH_CHECK_HIP(hipGetLastError());
-        return NLSH_OK;
-    }
-    if (c.max_tasks > 0) {
+    if ((c.phases & NLSH_PHASE_SCAN) && c.max_tasks > 0) {
         if (c.ev_begin) NLSH_CHECK_HIP(hipEventRecord((hipEvent_t)c.ev_begin, s));
         if (c.tiled) {
             const unsigned grid = (unsigned)((c.max_tasks + 127) / 128 * 128);  // one workgroup per task (the chunked XCD map works on 8 x 16 ids)
@@ -717,7 +713,7 @@ int bucket_scan_run(const BucketScanCall &c) {
         }
         if (c.ev_end) NLSH_CHECK_HIP(hipEventRecord((hipEvent_t)c.ev_end, s));
     }
-    hipLaunchKernelGGL(bmerge_kernel, dim3((unsigned)((c.Q + 3) / 4)), dim3(256), 0, s, a);
+    if (c.phases & NLSH_PHASE_MERGE) hipLaunchKernelGGL(bmerge_kernel, dim3((unsigned)((c.Q + 3) / 4)), dim3(256), 0, s, a);
     NLSH_CHECK_HIP(hipGetLastError());
     return NLSH_OK;
 }

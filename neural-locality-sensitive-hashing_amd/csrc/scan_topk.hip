@@ -277,7 +277,7 @@ extern "C" int nlsh_scan_topk_phase(const float *corpus_sorted, int64_t row_stri
                               int P, int k, int metric, int algo, int seg_rows, float *out_dist, int32_t *out_idx,
                               uint64_t *out_keys, int32_t *out_ncand, int32_t *status, void *workspace, size_t workspace_bytes,
                               int64_t max_tasks, void *ev_scan_begin, void *ev_scan_end, nlsh_stream_t stream, int phases) {
-    NLSH_REQUIRE(phases >= 1 && phases <= (NLSH_PHASE_PLAN | NLSH_PHASE_SCAN), NLSH_E_INVALID, "scan_topk: phases=%d", phases);
+    NLSH_REQUIRE(phases >= 1 && phases <= (NLSH_PHASE_PLAN | NLSH_PHASE_SCAN | NLSH_PHASE_MERGE), NLSH_E_INVALID, "scan_topk: phases=%d", phases);
     NLSH_REQUIRE(Q >= 0 && Q < (1ll << 31), NLSH_E_INVALID, "scan_topk: Q=%lld", (long long)Q);
     NLSH_REQUIRE(d >= 1 && d <= NLSH_MAX_DIM, NLSH_E_UNSUPPORTED, "scan_topk: d=%d not in [1,%d]", d, NLSH_MAX_DIM);
     NLSH_REQUIRE(k >= 1 && k <= NLSH_MAX_K, NLSH_E_UNSUPPORTED, "scan_topk: k=%d not in [1,%d]", k, NLSH_MAX_K);
@@ -328,8 +328,9 @@ extern "C" int nlsh_scan_topk_phase(const float *corpus_sorted, int64_t row_stri
         if (metric == NLSH_METRIC_L2_EPS) launch_scan<NLSH_METRIC_L2_EPS>(a, d4, grid, s);
         else launch_scan<NLSH_METRIC_COSINE>(a, d4, grid, s);
         if (ev_scan_end) NLSH_CHECK_HIP(hipEventRecord((hipEvent_t)ev_scan_end, s));
-        hipLaunchKernelGGL(merge_segments_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, s, a);
     }
+    if ((phases & NLSH_PHASE_MERGE) && max_tasks > 0)
+        hipLaunchKernelGGL(merge_segments_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, s, a);
     NLSH_CHECK_HIP(hipGetLastError());
     return NLSH_OK;
 }
@@ -344,7 +345,7 @@ extern "C" int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, in
     return nlsh_scan_topk_phase(corpus_sorted, row_stride, d, gid, uniq_keys, offsets, bucket_order, n_buckets, inv_norm, queries,
                                 q_stride, Q, qkeys, nkeys, P, k, metric, algo, seg_rows, out_dist, out_idx, out_keys, out_ncand,
                                 status, workspace, workspace_bytes, max_tasks, ev_scan_begin, ev_scan_end, stream,
-                                NLSH_PHASE_PLAN | NLSH_PHASE_SCAN);
+                                NLSH_PHASE_PLAN | NLSH_PHASE_SCAN | NLSH_PHASE_MERGE);
 }
 
 extern "C" int nlsh_merge_topk(const uint64_t *keys_in, int64_t row_stride, int G, int64_t Q, int k, const int32_t *ncand_in,

@@ -17,7 +17,8 @@ KEY_REF_INT16, KEY_FULL = 0, 1
 METRIC_L2_EPS, METRIC_COSINE = 0, 1
 SCAN_QUERY_MAJOR, SCAN_BUCKET_MAJOR, SCAN_BUCKET_TILED = 0, 1, 2
 MAX_LAYERS, MAX_HASH_BITS, MAX_PROBES, MAX_K, MAX_DIM, MAX_WIDTH = 8, 32, 64, 64, 1024, 632
-PHASE_PLAN, PHASE_SCAN = 1, 2
+PHASE_PLAN, PHASE_SCAN, PHASE_MERGE = 1, 2, 4
+PHASE_ALL = 7
 MAX_ENCODE_PROBES = 128  # nlsh_encode_hash generates up to this many keys per row; the scan takes them in slices of MAX_PROBES
 
 # every symbol include/nlsh_hip.h declares (tests/test_capi_symbols.py checks the header against this)

@@ -254,7 +254,7 @@ class Indexer:
             if ws is None or ws.numel() < ws_bytes or ws.device != dev:
                 ws = self._ws[stream] = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
             self._scan_launch(q, keys, nkeys, k, algo, max_tasks, out_dist, out_idx, out_keys, ncand, status, ws,
-                              _capi.PHASE_PLAN | _capi.PHASE_SCAN, events)
+                              _capi.PHASE_ALL, events)
             if not check or Q == 0:
                 break
             needed, overflow = status.cpu().tolist()

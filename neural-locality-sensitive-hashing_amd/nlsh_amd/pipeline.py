@@ -1,18 +1,21 @@
-"""Two-stage software pipeline of query batches over two HIP streams.
+"""Three-stage software pipeline of query batches over three HIP streams.
 
-A batch is `encode_hash` + the PLAN phase of the scan (bucket lookup, task table: five small latency-bound kernels)
-followed by the SCAN phase (the scan kernel and the merge) and, on a sharded index, the all-gather + shard merge.
-Run back to back on one stream the first group costs ~0.1 ms during which most of the chip idles.  Here batch i+1's
-front stage runs on the FRONT stream while batch i's back stage runs on the BACK stream:
+A batch is `encode_hash` + the PLAN phase of the scan (bucket lookup, task table: five small latency-bound kernels),
+the SCAN phase (the scan kernel, which fills the chip), and the MERGE phase (per-query merge of the partial lists)
+followed, on a sharded index, by the all-gather + shard merge.  Run back to back on one stream, the first and the
+last group cost ~0.1 ms per batch during which most of the chip idles (and the collective's latency is exposed).
+Here the three groups of consecutive batches run on three streams:
 
-    front:  encode(i+1) plan(i+1) | encode(i+2) plan(i+2) | ...
-    back :  scan(i) merge(i) [all-gather(i)] | scan(i+1) ...
+    front:  encode(i+1) plan(i+1)           | encode(i+2) plan(i+2) | ...
+    mid  :  scan(i)                         | scan(i+1)             | ...
+    tail :  merge(i-1) [all-gather(i-1)]    | merge(i) ...          | ...
 
-Scan kernels never overlap each other (they are all on the back stream), so their HIP-event durations stay
-meaningful; `depth` slots own the per-batch buffers (key table, task-table workspace, outputs), a slot is reused
-only after its back stage has finished (event).  Results are bit-identical to `Indexer.query_tensors`: the kernels
-and their arguments are the same, only the stream they run on differs.  No reference counterpart (the reference
-answers one query at a time, nlsh/indexer.py:62-95).
+Scan kernels never overlap each other (they are all on the mid stream), so their HIP-event durations stay
+meaningful (they share the chip with the small kernels of the neighbouring batches: +7 %).  `depth` slots own the
+per-batch buffers (key table, task-table workspace, outputs); a slot is reused only after its tail stage has
+finished (event).  Results are bit-identical to `Indexer.query_tensors`: the kernels and their arguments are the
+same, only the stream they run on differs.  No reference counterpart (the reference answers one query at a time,
+nlsh/indexer.py:62-95).
 """
 from typing import Callable, Optional
 
@@ -27,13 +30,15 @@ class _Slot:
 
 class QueryPipeline:
 
-    def __init__(self, indexer, sample_queries, k=10, hash_times=10, depth=2, want_keys=False,
+    def __init__(self, indexer, sample_queries, k=10, hash_times=10, depth=3, want_keys=False,
                  exchange: Optional[Callable] = None):
         """`sample_queries`: a batch of the shape every later batch has (sizes the task table with one ordinary,
         checked call).  `exchange(keys64, ncand) -> (dist, idx, ncand)`: the sharded index's all-gather + merge,
-        run on the back stream (needs the 64-bit keys, so it implies want_keys)."""
+        run on the tail stream (needs the 64-bit keys, so it implies want_keys)."""
         if hash_times > _capi.MAX_PROBES:
             raise _capi.NlshHipError(_capi.E_UNSUPPORTED, f"pipelined batches take hash_times <= {_capi.MAX_PROBES}")
+        if depth < 2:
+            raise ValueError("depth must be >= 2 (3 keeps all three stages busy)")
         self.indexer, self.k, self.P, self.exchange = indexer, k, hash_times, exchange
         q = sample_queries
         if q.dtype != torch.float32 or q.stride(1) != 1:
@@ -45,8 +50,11 @@ class QueryPipeline:
         self.algo = indexer.last_algo
         self.max_tasks = indexer._max_tasks[self.algo]
         ws_bytes = _capi.lib().nlsh_scan_workspace(self.Q, self.P, k, self.max_tasks, indexer.n_buckets, self.d)
-        # the front stage is many small workgroups that must slip in beside the scan: give its queue the higher priority
-        self.front, self.back = torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev, priority=0)
+        # the front and tail stages are small workgroups that must slip in beside the scan: their queues get the
+        # higher priority
+        self.front = torch.cuda.Stream(device=dev, priority=-1)
+        self.mid = torch.cuda.Stream(device=dev, priority=0)
+        self.tail = torch.cuda.Stream(device=dev, priority=-1)
         self.slots = []
         for _ in range(depth):
             s = _Slot()
@@ -58,41 +66,46 @@ class QueryPipeline:
             s.ncand = torch.empty((self.Q,), dtype=torch.int32, device=dev)
             s.status = torch.zeros((2,), dtype=torch.int32, device=dev)
             s.ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
-            s.planned, s.done = torch.cuda.Event(), torch.cuda.Event()
+            s.planned, s.scanned, s.done = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
             s.done.record(torch.cuda.current_stream(dev))
             self.slots.append(s)
         self.n_submitted = 0
         self.last_slot = None
 
+    def _launch(self, queries, s, phases, events=None):
+        self.indexer._scan_launch(queries, s.keys, s.nkeys, self.k, self.algo, self.max_tasks, s.out_dist, s.out_idx,
+                                  s.out_keys, s.ncand, s.status, s.ws, phases, events)
+
     def submit(self, queries, seed=None, events=None):
         """Enqueue one batch; returns (dist, idx, ncand, keys64 | None) -- device tensors owned by the batch's slot
-        (or fresh ones from `exchange`), valid once the back stream has passed the batch (`synchronize()`), and
-        overwritten `depth` submits later."""
+        (or fresh ones from `exchange`), valid once the tail stream has passed the batch (`synchronize()`), and
+        overwritten `depth` submits later.  `events`: (begin, end) pair recorded around the scan kernel."""
         if queries.shape != (self.Q, self.d) or queries.dtype != torch.float32 or queries.stride(1) != 1:
             raise ValueError("batch shape/dtype differs from the pipeline's sample batch")
-        ix, s = self.indexer, self.slots[self.n_submitted % len(self.slots)]
+        s = self.slots[self.n_submitted % len(self.slots)]
         self.n_submitted += 1
-        caller = torch.cuda.current_stream(queries.device)
-        self.front.wait_stream(caller)      # the batch itself may still be in flight on the caller's stream
-        self.front.wait_event(s.done)       # the slot's previous batch has left the back stage
+        self.front.wait_stream(torch.cuda.current_stream(queries.device))   # the batch may still be in flight there
+        self.front.wait_event(s.done)                                       # the slot's previous batch has left the tail
         with torch.cuda.stream(self.front):
-            ix.hash_device(queries, hash_times=self.P, seed=seed, out=(s.keys, s.nkeys))
-            ix._scan_launch(queries, s.keys, s.nkeys, self.k, self.algo, self.max_tasks, s.out_dist, s.out_idx, s.out_keys,
-                            s.ncand, s.status, s.ws, _capi.PHASE_PLAN)
+            self.indexer.hash_device(queries, hash_times=self.P, seed=seed, out=(s.keys, s.nkeys))
+            self._launch(queries, s, _capi.PHASE_PLAN)
             s.planned.record(self.front)
-        self.back.wait_event(s.planned)
-        with torch.cuda.stream(self.back):
-            ix._scan_launch(queries, s.keys, s.nkeys, self.k, self.algo, self.max_tasks, s.out_dist, s.out_idx, s.out_keys,
-                            s.ncand, s.status, s.ws, _capi.PHASE_SCAN, events)
+        self.mid.wait_event(s.planned)
+        with torch.cuda.stream(self.mid):
+            self._launch(queries, s, _capi.PHASE_SCAN, events)
+            s.scanned.record(self.mid)
+        self.tail.wait_event(s.scanned)
+        with torch.cuda.stream(self.tail):
+            self._launch(queries, s, _capi.PHASE_MERGE)
             out = (s.out_dist, s.out_idx, s.ncand, s.out_keys)
             if self.exchange is not None:
                 out = tuple(self.exchange(s.out_keys, s.ncand)) + (None,)
-            s.done.record(self.back)
+            s.done.record(self.tail)
         self.last_slot = s
         return out
 
     def synchronize(self):
-        self.back.synchronize()
+        self.tail.synchronize()
 
     def overflowed(self) -> bool:
         """True if any slot's last batch did not fit the task table (results incomplete: rebuild the pipeline)."""

@@ -472,7 +472,8 @@ def test_save_then_load_checkpoint_roundtrip(tmp_path):
 
 
 def test_pipelined_batches_are_bit_identical_to_sequential_calls():
-    """nlsh_amd/pipeline.py: front stream encode + PLAN, back stream SCAN -- same kernels, same arguments."""
+    """nlsh_amd/pipeline.py: encode + PLAN, SCAN and MERGE of consecutive batches on three streams -- same kernels,
+    same arguments."""
     from nlsh_amd.data import Glove, SIFT
     from nlsh_amd.indexer import Indexer
     from nlsh_amd.pipeline import QueryPipeline
@@ -486,19 +487,14 @@ def test_pipelined_batches_are_bit_identical_to_sequential_calls():
         batches = [dev(gen(Q, d, seed=50 + i)) for i in range(5)]
         want = [indexer.query_tensors(b, k=k, hash_times=P, seed=900 + i, want_keys=True) for i, b in enumerate(batches)]
         want = [tuple(t.clone() for t in w) for w in want]
-        pipe = QueryPipeline(indexer, batches[0], k=k, hash_times=P, depth=2, want_keys=True)
-        got = []
-        for i, b in enumerate(batches):
-            out = pipe.submit(b, seed=900 + i)
-            if i >= 1:                       # a slot is overwritten `depth` submits later: read batch i-1 now
-                pipe.back.wait_event(pipe.slots[(i - 1) % 2].done)
-            got.append(out)
-            if i % 2 == 1:
-                pipe.synchronize()
-                for j in (i - 1, i):
-                    for a, w in zip(got[j], want[j]):
-                        assert torch.equal(a, w), (metric, algo, j)
-        pipe.synchronize()
-        for a, w in zip(got[4], want[4]):
-            assert torch.equal(a, w)
-        assert not pipe.overflowed()
+        for depth in (2, 3):
+            pipe = QueryPipeline(indexer, batches[0], k=k, hash_times=P, depth=depth, want_keys=True)
+            got = []
+            for i, b in enumerate(batches):
+                got.append(pipe.submit(b, seed=900 + i))
+                if (i + 1) % depth == 0 or i + 1 == len(batches):   # a slot is overwritten `depth` submits later: read now
+                    pipe.synchronize()
+                    for j in range(i + 1 - ((i % depth) + 1), i + 1):
+                        for a, w in zip(got[j], want[j]):
+                            assert torch.equal(a, w), (metric, algo, depth, j)
+            assert not pipe.overflowed()

@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--q", type=int, default=10_000)
     ap.add_argument("--shard", default="buckets", choices=["buckets", "rows"])
-    ap.add_argument("--pipeline", action="store_true", help="two-stage pipeline over two streams (nlsh_amd/pipeline.py)")
+    ap.add_argument("--pipeline", action="store_true", help="three-stage pipeline over three streams (nlsh_amd/pipeline.py)")
     args = ap.parse_args()
     from nlsh_amd import io, synth
     from nlsh_amd.data import SIFT
@@ -61,7 +61,7 @@ def main():
     pipe = None
     if args.pipeline:
         from nlsh_amd.pipeline import QueryPipeline
-        pipe = QueryPipeline(indexer, queries, k=10, hash_times=10, depth=2, want_keys=True)
+        pipe = QueryPipeline(indexer, queries, k=10, hash_times=10, depth=3, want_keys=True)
         for i in range(3):
             pipe.submit(queries, seed=50 + i)
         torch.cuda.synchronize()
