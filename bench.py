@@ -7,11 +7,11 @@
 A "step" = one pass of the hot path over the whole query batch (BASELINE.json configs[1]:
 SIFT1M-shaped, 1M x 128-d corpus, 10k queries, 16-bit hash, k=10, hash_times=10):
 encode_hash (MLP on fp32 MFMA + bits + multi-probe keys) -> plan -> scan_topk -> merge, all
-device-resident (inputs in HBM before the timed region, results left in HBM).  The K timed steps run as a
-three-stage pipeline over three HIP streams (nlsh_amd/pipeline.py): encode + plan of batch i+1 and merge (+ all-gather
-at N>1) of batch i-1 beside the scan of batch i -- every kernel of every step runs inside the timed region, scan
-kernels never overlap each other, results are bit-identical to sequential calls.  `--pipeline off`
-runs every kernel of a step back to back on one stream.
+device-resident (inputs in HBM before the timed region, results left in HBM).  At N=1 every kernel of a step runs
+back to back on one stream (each kernel alone on the chip: undisturbed roofline timings).  At N>1 the K timed steps run
+as a three-stage pipeline over three HIP streams (nlsh_amd/pipeline.py): encode + plan of batch i+1 and merge +
+all-gather of batch i-1 beside the scan of batch i -- every kernel of every step runs inside the timed region, scan
+kernels never overlap each other, results are bit-identical to sequential calls (`--pipeline on|off` forces either).
 N>1: corpus buckets sharded over the ranks (whole buckets per rank, one build-time all-to-all; `--shard rows` keeps
 contiguous row ranges instead), every rank answers all queries over its shard, one all-gather (RCCL) of
 the per-rank top-k + merge per step ("strong" scaling: total work fixed).
@@ -57,10 +57,12 @@ def parse():
     ap.add_argument("--seg-rows", type=int, default=0)
     ap.add_argument("--shard", default="buckets", choices=["buckets", "rows"],
                     help="N>1 partition of the corpus: whole buckets per rank (default) or contiguous row ranges")
-    ap.add_argument("--pipeline", default="on", choices=["on", "off"],
+    ap.add_argument("--pipeline", default="auto", choices=["auto", "on", "off"],
                     help="on: three-stage pipeline over three HIP streams, encode+plan of batch i+1 and merge(+all-gather) of "
                          "batch i-1 on high-priority streams beside the scan of batch i.  off: every kernel of a step back "
-                         "to back on one stream (each kernel alone on the chip)")
+                         "to back on one stream (each kernel alone on the chip).  auto: on for N>1 (hides the collective and "
+                         "the per-batch fixed kernels), off for N=1 (worth +2..10 %% there, but the scan kernel's roofline "
+                         "timing is then taken while it shares the chip: --also-other reports the other mode too)")
     ap.add_argument("--also-other", action="store_true", help="additionally time the K steps in the other mode (reported as `other_mode`)")
     ap.add_argument("--algo", default=None, choices=["query", "bucket", "tiled"], help="force a scan schedule (default: auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -173,7 +175,7 @@ def main():
             ev_x[i][1].record()
         return out_
 
-    use_pipeline = args.pipeline == "on"
+    use_pipeline = args.pipeline == "on" or (args.pipeline == "auto" and world > 1)
     if use_pipeline:
         from nlsh_amd.pipeline import QueryPipeline
         pipe = QueryPipeline(indexer, queries, k=k, hash_times=P, depth=3, exchange=exchange if world > 1 else None)
