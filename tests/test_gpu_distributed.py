@@ -1,0 +1,85 @@
+"""N>1 path on the GPU: two ranks (gloo rendezvous, both on cuda:0 -- the box has one GPU) build a bucket-sharded index
+with the real build-time exchange, answer batches through the three-stage pipeline with the all-gather + shard merge
+in its tail stage, and must reproduce the single-index results bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _case():
+    for p in (ROOT, os.path.join(ROOT, "neural-locality-sensitive-hashing_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from nlsh_amd import synth
+    N, Q, d, H = 40000, 600, 128, 8
+    corpus, mean, std = synth.standardise(synth.sift_like(N, d, seed=61))
+    corpus[300:330] = corpus[25000:25030]                               # exact ties across shards
+    batches = [synth.standardise(synth.sift_like(Q, d, seed=62 + i), mean, std)[0] for i in range(4)]
+    Ws, bs = synth.make_weights([d, 64, H], seed=61)
+    return corpus, batches, Ws, bs, d, H
+
+
+def _hashing(Ws, bs, d, H):
+    from nlsh_amd import io
+    return io.hashing_from_weights(Ws, bs, compat=True)
+
+
+def _worker(rank, world, port, shard, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    corpus, batches, Ws, bs, d, H = _case()
+    from nlsh_amd.data import SIFT
+    from nlsh_amd.distributed import ShardedIndexer, gather_and_merge, shard_range
+    from nlsh_amd.pipeline import QueryPipeline
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    lo, hi = shard_range(len(corpus), rank, world)
+    sharded = ShardedIndexer(_hashing(Ws, bs, d, H), torch.from_numpy(corpus[lo:hi]).to(dev), SIFT.distance, id_base=lo, shard=shard)
+    k, P = 10, 6
+    qd = [torch.from_numpy(b).to(dev) for b in batches]
+    direct = [tuple(t.cpu().numpy() for t in sharded.query_tensors(b, k=k, hash_times=P, seed=70 + i)) for i, b in enumerate(qd)]
+    pipe = QueryPipeline(sharded.local, qd[0], k=k, hash_times=P, depth=3, exchange=lambda k64, nc: gather_and_merge(k64, nc, k))
+    piped = []
+    for i, b in enumerate(qd):
+        out = pipe.submit(b, seed=70 + i)
+        pipe.synchronize()                                               # exchange outputs are fresh tensors: read at once
+        piped.append(tuple(t.cpu().numpy() for t in out[:3]))
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "merged.npz"), **{f"{tag}{i}_{j}": a for tag, res in (("d", direct), ("p", piped))
+                                                         for i, r in enumerate(res) for j, a in enumerate(r)},
+                 rows=np.asarray([sharded.local._candidate_vectors_gpu.shape[0]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shard", ["buckets", "rows"])
+def test_two_rank_sharded_pipeline_equals_single_index(tmp_path, shard):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), shard, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "merged.npz")
+    corpus, batches, Ws, bs, d, H = _case()
+    from nlsh_amd.data import SIFT
+    from nlsh_amd.indexer import Indexer
+    dev = torch.device("cuda", 0)
+    single = Indexer(_hashing(Ws, bs, d, H), torch.from_numpy(corpus).to(dev), SIFT.distance)
+    for i, b in enumerate(batches):
+        dist_, idx_, nc_, _ = single.query_tensors(torch.from_numpy(b).to(dev), k=10, hash_times=6, seed=70 + i)
+        for tag in ("d", "p"):
+            assert np.array_equal(got[f"{tag}{i}_1"], idx_.cpu().numpy()), (tag, i)
+            assert np.array_equal(got[f"{tag}{i}_0"], dist_.cpu().numpy()), (tag, i)
+            assert np.array_equal(got[f"{tag}{i}_2"], nc_.cpu().numpy()), (tag, i)
+    assert 0.4 * len(corpus) < int(got["rows"][0]) < 0.6 * len(corpus)
