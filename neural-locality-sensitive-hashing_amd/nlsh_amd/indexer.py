@@ -85,7 +85,7 @@ def build_index(indexes, cuda=True) -> Dict[int, torch.Tensor]:
 class Indexer:
 
     def __init__(self, hashing, candidate_vectors_gpu, distance_func, compat=True, metric: Optional[str] = None,
-                 seg_rows: int = 0, id_base: int = 0, algo: Optional[str] = None, stats_scale: float = 1.0,
+                 seg_rows: int = 0, id_base: int = 0, algo: Optional[str] = None,
                  row_ids: Optional[torch.Tensor] = None, schedule_stats: Optional[Tuple[float, float]] = None):
         self._hashing = hashing
         self._candidate_vectors_gpu = candidate_vectors_gpu
@@ -94,11 +94,9 @@ class Indexer:
         self.metric = metric or metric_of(distance_func)
         self.seg_rows = seg_rows
         self.algo = algo            # None = choose per batch; "query" | "bucket" | "tiled" force a schedule
-        # number of equal shards the full corpus was split into: the schedule is chosen from the statistics of
-        # the WHOLE corpus, so every shard count runs the same arithmetic and results stay bit-identical
-        self.stats_scale = float(stats_scale)
-        # exact form of the same idea: (size-biased bucket size, row count) of the WHOLE corpus, as the sharded
-        # builds compute them from the all-gathered keys; overrides stats_scale when given
+        # (size-biased bucket size, row count) of the WHOLE corpus when this index holds a shard of it (the sharded
+        # builds compute them from the all-gathered keys): the schedule is chosen from whole-corpus statistics, so every
+        # shard count runs the same arithmetic and results stay bit-identical
         self.schedule_stats = schedule_stats
         self.id_base = int(id_base)
         # global row id of every local row (int32 [N], device) when the shard is not a contiguous range
@@ -198,8 +196,8 @@ class Indexer:
         if self.schedule_stats is not None:
             e_sb, n = float(self.schedule_stats[0]), max(float(self.schedule_stats[1]), 1.0)
         else:
-            e_sb = self._size_biased_bucket() * self.stats_scale
-            n = max(float(self.bucket_sizes.sum()), 1.0) * self.stats_scale
+            e_sb = self._size_biased_bucket()
+            n = max(float(self.bucket_sizes.sum()), 1.0)
         reuse = Q * P * e_sb / n
         if e_sb >= 256 and reuse >= 8.0:
             return _capi.SCAN_BUCKET_TILED
