@@ -157,9 +157,9 @@ int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, int d, const 
                    void *ev_scan_begin, void *ev_scan_end, nlsh_stream_t stream);
 
 /* The same call cut in three, for callers that pipeline batches over streams: NLSH_PHASE_PLAN runs everything up
- * to the scan kernel (bucket lookup, candidate counts, task table; touches out_ncand, status and the workspace),
+ * to the scan kernel (bucket lookup, task table; touches status and the workspace, the query-major schedule also out_ncand),
  * NLSH_PHASE_SCAN the scan kernel (reads what PLAN left in the workspace, leaves per-task partial top-k lists there),
- * NLSH_PHASE_MERGE the per-query merge of those lists (writes out_dist / out_idx / out_keys).  All take the identical
+ * NLSH_PHASE_MERGE the per-query merge of those lists (writes out_dist / out_idx / out_keys / out_ncand).  All take the identical
  * argument list and may be combined; each must be ordered after the previous one (an event when they run on
  * different streams), and a workspace belongs to one batch until its MERGE has finished.  All three bits =
  * nlsh_scan_topk.  The plan of batch i+1 and the merge of batch i-1 (latency-bound, small kernels) then overlap the

@@ -69,7 +69,7 @@ struct BArgs {
     int32_t *out_ncand;
     int32_t *status;
     int32_t *pbkt, *inv_q, *bcount, *pairoff, *taskoff, *bgroups, *counters;
-    int4 *prec;  // [Q*P] per (query, probe): {first task of its query group, slot in the group, row segments, query groups}; .z = 0: no bucket
+    int4 *prec;  // [Q*P] per (query, probe): {first task of its query group, slot in the group, bucket rows, query groups}; .z = 0: no bucket
     int4 *task;
     uint64_t *partial;
     long long max_tasks;
@@ -83,19 +83,23 @@ struct BArgs {
 };
 
 // one launch instead of five hipMemsetAsync nodes (4.8 us each on this runtime): shared bounds to KEY_NONE,
-// candidate counts, bucket probe counts, cursors and the status words to zero
+// bucket probe counts, cursors and the status words to zero
 __global__ __launch_bounds__(256) void binit_kernel(BArgs a) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < a.Q) {
-        a.tauq[i] = KEY_NONE;
-        a.out_ncand[i] = 0;
-    }
+    if (i < a.Q) a.tauq[i] = KEY_NONE;
     if (i < a.nb) a.bcount[i] = 0;
     if (i < 4) a.counters[i] = 0;
     if (i < 2) a.status[i] = 0;
 }
 
-__global__ __launch_bounds__(256) void bplan_kernel(BArgs a) {
+// Bucket lookup of every (query, probe): binary search of the key in uniq[nb].  The first ~10 of its ~13 steps run on a
+// coarse table in LDS (every `stride`-th key, <= 1024 entries, loaded once per workgroup), the last log2(stride) on the
+// stride-long run in global memory: 3-4 dependent global loads per thread instead of 13.
+__global__ __launch_bounds__(256) void bplan_kernel(BArgs a, int stride) {
+    __shared__ int32_t coarse[1024];
+    const int nco = (a.nb + stride - 1) / stride;
+    for (int i = threadIdx.x; i < nco; i += 256) coarse[i] = a.uniq[(long long)i * stride];
+    __syncthreads();
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= a.Q * a.P) return;
     const long long q = idx / a.P;
@@ -105,17 +109,24 @@ __global__ __launch_bounds__(256) void bplan_kernel(BArgs a) {
     int b = -1;
     if (p < nk) {
         const int32_t key = a.qkeys[idx];
-        int lo = 0, hi = a.nb;
-        while (lo < hi) {
-            int mid = (lo + hi) >> 1;
-            if (a.uniq[mid] < key) lo = mid + 1; else hi = mid;
+        int lo = 0, hi = nco;
+        while (lo < hi) {  // first coarse entry > key
+            const int mid = (lo + hi) >> 1;
+            if (coarse[mid] <= key) lo = mid + 1; else hi = mid;
         }
-        if (lo < a.nb && a.uniq[lo] == key) {  // unknown key = empty bucket (indexer.py:61,68)
-            const int sz = a.offsets[lo + 1] - a.offsets[lo];
-            if (sz > 0) {
-                b = lo;
-                atomicAdd(&a.bcount[lo], 1);
-                atomicAdd(&a.out_ncand[q], sz);  // n_candidates (indexer.py:71,94)
+        if (lo > 0) {  // the key, if present, lies in the run that starts at coarse entry lo-1
+            lo = (lo - 1) * stride;
+            hi = min(a.nb, lo + stride);
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (a.uniq[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            if (lo < a.nb && a.uniq[lo] == key) {  // unknown key = empty bucket (indexer.py:61,68)
+                const int sz = a.offsets[lo + 1] - a.offsets[lo];
+                if (sz > 0) {
+                    b = lo;
+                    atomicAdd(&a.bcount[lo], 1);
+                }
             }
         }
     }
@@ -222,7 +233,7 @@ __global__ __launch_bounds__(256) void bscatter_kernel(BArgs a) {
     // what bmerge needs to find this probe's partial lists, resolved here so that it has one load level less:
     // task of (segment si, group gi) = taskoff + si * ngroups + gi
     const int gi = rel / a.QB;
-    a.prec[idx] = make_int4(a.taskoff[b] + gi, rel - gi * a.QB, (a.offsets[b + 1] - a.offsets[b] + a.seg - 1) / a.seg, a.bgroups[b]);
+    a.prec[idx] = make_int4(a.taskoff[b] + gi, rel - gi * a.QB, a.offsets[b + 1] - a.offsets[b], a.bgroups[b]);
 }
 
 // One task: stream `nrows` rows starting at row0 once, score them against the nq <= QB queries of
@@ -579,9 +590,17 @@ __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
     // lane p holds probe p's record (written by bscatter): where its partial lists are
     int ns_l = 0, j_l = 0, ng_l = 0;
     long long t0_l = 0;
+    int size_l = 0;
     if (lane < nk) {
         const int4 rec = a.prec[q * a.P + lane];
-        t0_l = rec.x; j_l = rec.y; ns_l = rec.z; ng_l = rec.w;
+        t0_l = rec.x; j_l = rec.y; size_l = rec.z; ng_l = rec.w;
+        ns_l = (size_l + a.seg - 1) / a.seg;
+    }
+    {   // n_candidates of the query (indexer.py:71,94) = rows of its probed buckets
+        int c = size_l;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m);
+        if (lane == 0) a.out_ncand[q] = c;
     }
     // The query's partial lists (one per probe and row segment) are numbered 0..L-1 by an inclusive scan of the
     // per-probe segment counts.  R = 64/k lists are fetched per round with ONE load instruction (lane -> (list,
@@ -690,7 +709,9 @@ int bucket_scan_run(const BucketScanCall &c) {
         if (n_init < 4) n_init = 4;
         hipLaunchKernelGGL(binit_kernel, dim3((unsigned)((n_init + 255) / 256)), dim3(256), 0, s, a);
         const unsigned gp = (unsigned)((c.Q * c.P + 255) / 256);
-        hipLaunchKernelGGL(bplan_kernel, dim3(gp), dim3(256), 0, s, a);
+        int stride = 1;
+        while ((long long)stride * 1024 < c.nb) stride <<= 1;  // coarse table of bplan: <= 1024 entries
+        hipLaunchKernelGGL(bplan_kernel, dim3(gp), dim3(256), 0, s, a, stride);
         if (c.nb > 0) {
             const unsigned gb = (unsigned)((c.nb + 255) / 256);
             hipLaunchKernelGGL(bcount_kernel, dim3(gb), dim3(256), 0, s, a);
