@@ -269,13 +269,14 @@ def main():
 
     # HBM traffic per launch: PMC numbers cannot be collected from inside the process; they come from
     # the committed rocprofv3 --pmc passes of this round (profiles/traffic_r01.json) when the workload matches.
-    traffic = None
+    traffic, valu_insts = None, None
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
         w = tr["workload"]
         if (w["N"], w["d"], w["Q"], w["H"], w["hash_times"]) == (N, d, Q, H, P) and world == 1 and "learned" in hash_desc \
                 and args.workload == "sift1m":
             traffic = tr["traffic_bytes_per_launch"].get(str(indexer.last_algo))
+            valu_insts = tr.get("valu_wave_instructions_per_launch", {}).get(str(indexer.last_algo))
     except (OSError, KeyError, ValueError):
         pass
 
@@ -311,6 +312,9 @@ def main():
                                            else "sequential: every kernel of a step back to back on one stream")
         if other_mode is not None:
             result["other_mode"] = other_mode
+        if valu_insts:   # the tiled kernel is fp32-VALU-bound: its issue-rate utilisation beside the HBM figure the contract asks for
+            result["roofline"]["valu_wave_instructions_per_launch"] = valu_insts
+            result["roofline"]["valu_issue_frac"] = valu_insts * 2.0 / (1024 * scan_avg_ms * 1e-3 * 2.4e9)
         if enc is not None:
             result["encoder"] = enc
             result["roofline"]["hbm_copy_measured_GBps"] = copy_gbps
