@@ -53,7 +53,7 @@ enum { NLSH_SCAN_QUERY_MAJOR = 0, NLSH_SCAN_BUCKET_MAJOR = 1, NLSH_SCAN_BUCKET_T
 #define NLSH_MAX_ENCODE_PROBES 128  /* hash_times nlsh_encode_hash generates (eval.py:148 sweeps 1..100); scan in slices of 64 */
 #define NLSH_MAX_K 64
 #define NLSH_MAX_DIM 1024   /* vector dimension of corpus / queries for the scan */
-#define NLSH_MAX_WIDTH 632  /* widest encoder layer (input, hidden) the LDS-resident MLP supports */
+#define NLSH_MAX_WIDTH 632  /* widest HIDDEN encoder layer the LDS-resident MLP supports (the input may be NLSH_MAX_DIM wide) */
 
 int nlsh_abi_version(void);
 const char *nlsh_last_error(void);
@@ -86,7 +86,7 @@ int nlsh_encoder_pack(int n_layers, const int *dims, const float *const *W, cons
  * Probes 1..n_probes-1 are Bernoulli(p) draws from a Philox4x32-10 stream keyed by `seed`,
  * counter (row0 + row, probe, word): reproducible across devices and ranks.  Rows with index
  * >= n_multi_rows are single-probe (Indexer.hash's trailing-batch rule, nlsh/indexer.py:51-53).
- * Limits: H <= 32, n_probes <= NLSH_MAX_ENCODE_PROBES, every dims[l] (l < n_layers) <= NLSH_MAX_WIDTH. */
+ * Limits: H <= 32, n_probes <= NLSH_MAX_ENCODE_PROBES, dims[0] <= NLSH_MAX_DIM, hidden dims[l] <= NLSH_MAX_WIDTH. */
 int nlsh_encode_hash(const float *x, int64_t n, int64_t x_stride, int n_layers, const int *dims,
                      const float *packed, int act, int key_mode, int n_probes, int64_t n_multi_rows,
                      uint64_t seed, int64_t row0, float *z_out, float *probs_out, uint32_t *code_out,

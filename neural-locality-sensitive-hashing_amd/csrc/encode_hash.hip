@@ -430,7 +430,8 @@ static int check_dims(int n_layers, const int *dims) {
                  "encoder: n_layers=%d out of range [1,%d]", n_layers, NLSH_MAX_LAYERS);
     for (int l = 0; l <= n_layers; ++l) NLSH_REQUIRE(dims[l] >= 1, NLSH_E_INVALID, "encoder: dims[%d]=%d", l, dims[l]);
     for (int l = 0; l < n_layers; ++l)
-        NLSH_REQUIRE(dims[l] <= NLSH_MAX_WIDTH, NLSH_E_UNSUPPORTED, "encoder: layer input width %d > %d (LDS-resident MLP)", dims[l], NLSH_MAX_WIDTH);
+        NLSH_REQUIRE(dims[l] <= (l == 0 ? NLSH_MAX_DIM : NLSH_MAX_WIDTH), NLSH_E_UNSUPPORTED,
+                     "encoder: layer input width %d > %d (LDS-resident MLP)", dims[l], l == 0 ? NLSH_MAX_DIM : NLSH_MAX_WIDTH);
     NLSH_REQUIRE(dims[n_layers] <= NLSH_MAX_HASH_BITS, NLSH_E_UNSUPPORTED, "encoder: hash_size %d > %d", dims[n_layers], NLSH_MAX_HASH_BITS);
     return NLSH_OK;
 }

@@ -86,7 +86,7 @@ def test_encode_hash_ragged_sizes_bit_exact(n_rows):
 
 
 @pytest.mark.parametrize("dims", [[25, 96, 8], [50, 64, 64, 12], [200, 256, 256, 24], [96, 320, 40, 32],
-                                  [128, 600, 16], [100, 256, 256, 256, 256, 20], [128, 33, 1]])
+                                  [128, 600, 16], [100, 256, 256, 256, 256, 20], [128, 33, 1], [960, 256, 256, 32], [1024, 64, 7]])
 def test_encode_hash_odd_architectures(dims):
     Ws, bs = synth.make_weights(dims, seed=7)
     x = synth.glove_like(130, dims[0], seed=9)

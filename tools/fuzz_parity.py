@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU: random shapes (d, H, N, Q, k, hash_times, metric, schedule, key mode, skew) end to
+end against the CPU oracle on the device's own keys -- exact candidate counts, exact id lists wherever the oracle's
+(distance, id) order is unambiguous in fp32, distances within 2e-5, nothing closer missed.  Complements the fixed
+cases of tests/test_gpu_parity.py; run it after kernel changes:
+
+    python tools/fuzz_parity.py [--seconds 120 --seed 0]
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "neural-locality-sensitive-hashing_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from helpers import check_topk_against_candidates, make_hashing  # noqa: E402
+from nlsh_amd import synth  # noqa: E402
+from nlsh_amd.data import Glove, SIFT  # noqa: E402
+from nlsh_amd.indexer import Indexer  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+
+def one_case(rng, case_id):
+    metric = rng.choice(["l2", "cosine"])
+    d = int(rng.choice([8, 25, 50, 64, 96, 100, 128, 200, 300, 512, 960, 1024]))
+    H = int(rng.integers(3, 15))
+    compat = bool(rng.integers(0, 2))
+    N = int(rng.choice([1, 7, 300, 5000, 30000, 120000]))
+    Q = int(rng.choice([1, 5, 63, 64, 65, 700, 4096, 5000]))
+    k = int(rng.choice([1, 3, 10, 10, 10, 37, 64]))
+    P = int(rng.choice([1, 2, 6, 10, 10, 33, 64, 100]))
+    algo = rng.choice(["query", "bucket", "tiled", None])
+    hidden = tuple(int(v) for v in rng.choice([32, 64, 96, 320], size=int(rng.integers(1, 3))))
+    gen = synth.sift_like if metric == "l2" else synth.glove_like
+    corpus, queries = gen(N, d, seed=1000 + case_id), gen(Q, d, seed=2000 + case_id)
+    if N > 50 and rng.integers(0, 2):
+        corpus[N // 2:N // 2 + 20] = corpus[:20]                    # exact ties
+    if metric == "l2":
+        corpus, mean, std = synth.standardise(corpus)
+        queries, _, _ = synth.standardise(queries, mean, std)
+    Ws, bs = synth.make_weights([d] + list(hidden) + [H], seed=case_id)
+    if rng.integers(0, 3) == 0:                                     # skewed hash: a few huge buckets
+        Ws[-1][: H // 2] *= 0.05
+    hashing = make_hashing(d, hidden, H, Ws, bs, compat=compat)
+    desc = dict(metric=metric, d=d, H=H, compat=compat, N=N, Q=Q, k=k, P=P, algo=algo, hidden=hidden)
+    indexer = Indexer(hashing, torch.from_numpy(corpus).cuda(), SIFT.distance if metric == "l2" else Glove.distance, compat=compat, algo=algo)
+    qd = torch.from_numpy(queries).cuda()
+    keys, nkeys = indexer.hash_device(qd, hash_times=P, seed=case_id)
+    dist, idx, nc, _ = indexer.scan_tensors(qd, keys, nkeys, k=k)
+    kd, nk = keys.cpu().numpy().astype(np.int64), nkeys.cpu().numpy()
+    ck = indexer.corpus_keys.cpu().numpy().astype(np.int64)
+    if not compat:
+        kd, ck = kd & 0xFFFFFFFF, ck & 0xFFFFFFFF
+    perm, uniq, offs = oracle.build_csr(ck)
+    assert np.array_equal(indexer.perm.cpu().numpy(), perm), desc
+    od, oi, onc = oracle.query_batch(corpus, perm, uniq, offs, queries, kd, nk, k, metric)
+    assert np.array_equal(nc.cpu().numpy(), onc), desc
+    dist, idx = dist.cpu().numpy(), idx.cpu().numpy()
+    i2r = {int(u): perm[offs[i]:offs[i + 1]] for i, u in enumerate(uniq)}
+    exact = 0
+    for q in rng.choice(Q, size=min(Q, 64), replace=False):
+        rows = [i2r.get(int(kk), np.zeros(0, np.int32)) for kk in kd[q, :nk[q]]]
+        rows = np.concatenate(rows) if rows else np.zeros(0, np.int32)
+        _, d64 = oracle.distances(queries[q], corpus, rows, metric, f64=True)
+        check_topk_against_candidates(idx[q], dist[q], rows, d64, k)
+    exact = int((idx == oi).all(1).sum())
+    assert exact >= 0.9 * Q - 2, (desc, exact)      # fp32 near-ties may resolve either way; the checks above bound them
+    return desc, exact / Q
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    t0, n = time.time(), 0
+    while time.time() - t0 < args.seconds:
+        desc, frac = one_case(rng, args.seed * 100000 + n)
+        n += 1
+        print(f"[fuzz] case {n}: {desc} identical-to-oracle {frac:.3f}", flush=True)
+    print(f"[fuzz] {n} cases ok in {time.time() - t0:.0f}s")
+
+
+if __name__ == "__main__":
+    main()
