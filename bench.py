@@ -235,11 +235,15 @@ def main():
     # the API-level call (reference return type: Python lists; includes D2H + F7 handling)
     api_qps = None
     if world == 1:
-        indexer.query(queries, k=k, hash_times=P)      # warm-up (first use of the host-side torch ops)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ids_api, nc_api = indexer.query(queries, k=k, hash_times=P)
-        api_qps = Q / (time.perf_counter() - t0)
+        for _ in range(3):                              # warm-ups (first use of the host-side torch ops), SURVEY.md §8(d)
+            indexer.query(queries, k=k, hash_times=P)
+        times = []
+        for _ in range(10):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ids_api, nc_api = indexer.query(queries, k=k, hash_times=P)
+            times.append(time.perf_counter() - t0)
+        api_qps = Q / float(np.median(times))           # wall time of the reference-typed call incl. hashing, D2H, list building
 
     # encoder (MFMA) utilisation on this rank's corpus rows, and the box's measured HBM copy rate next to the spec peak
     enc = None
