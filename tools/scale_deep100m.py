@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""Scale run for BASELINE.json configs[4] on ONE GPU: Deep100M-shaped corpus (N x 96-d fp32, unit norm,
-HBM-resident: 38.4 GB + the bucket-sorted copy), 32-bit learned hash (full-width keys), 100k queries.
+"""Scale run for BASELINE.json configs[4]: Deep100M-shaped corpus (N x 96-d fp32, unit norm, HBM-resident: 38.4 GB +
+the bucket-sorted copy), 32-bit learned hash (full-width keys), 100k queries -- on ONE GPU, or sharded over the ranks
+of a torchrun launch (each rank generates its own row range on its device, the bucket partition's all-to-all moves the
+rows to their owners, batches go through the three-stage pipeline with the all-gather in the tail stage).
 
-    python tools/scale_deep100m.py [--n 100000000 --q 100000 --hash-size 32]
+    python tools/scale_deep100m.py [--rows 100000000 --queries 100000 --hash-size 32]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/scale_deep100m.py
 
 The corpus is generated ON THE DEVICE in chunks (a host copy would be 38 GB); the hash is trained on a
 1M-row sample with the minimal triplet trainer; recall is measured on a query sample against a chunked
@@ -24,29 +27,45 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
-def deep_manifold_device(n, d, seed, dev, latent_dim=10, n_clusters=256, spread=0.5, chunk=1 << 22, out=None):
-    """Unit-norm rows on a low-dimensional manifold, generated on the device (torch Philox generator)."""
+CHUNK = 1 << 22
+
+
+def _manifold_params(dev, d, latent_dim=10, n_clusters=256):
     g = torch.Generator(device=dev)
     g.manual_seed(777)
     A1 = torch.randn((latent_dim, 96), generator=g, device=dev)
     b1 = torch.rand((96,), generator=g, device=dev) * 2 - 1
     A2 = torch.randn((96, d), generator=g, device=dev) / 9.8
     cen = torch.randn((n_clusters, latent_dim), generator=g, device=dev)
-    g.manual_seed(seed)
-    out = torch.empty((n, d), dtype=torch.float32, device=dev) if out is None else out
-    for s in range(0, n, chunk):
-        e = min(n, s + chunk)
-        which = torch.randint(0, n_clusters, (e - s,), generator=g, device=dev)
-        z = cen[which] + spread * torch.randn((e - s, latent_dim), generator=g, device=dev)
-        x = torch.tanh(z @ A1 + b1) @ A2 + 0.02 * torch.randn((e - s, d), generator=g, device=dev)
-        out[s:e] = x / x.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    return A1, b1, A2, cen
+
+
+def deep_chunk(params, chunk_index, rows, d, seed, dev, spread=0.5):
+    """Rows [chunk_index*CHUNK, +rows) of the corpus: seeded per chunk, so any rank can (re)generate any range."""
+    A1, b1, A2, cen = params
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed * 1000003 + chunk_index)
+    which = torch.randint(0, cen.shape[0], (rows,), generator=g, device=dev)
+    z = cen[which] + spread * torch.randn((rows, cen.shape[1]), generator=g, device=dev)
+    x = torch.tanh(z @ A1 + b1) @ A2 + 0.02 * torch.randn((rows, d), generator=g, device=dev)
+    return x / x.norm(dim=1, keepdim=True).clamp_min(1e-12)
+
+
+def deep_manifold_device(lo, hi, d, seed, dev, params):
+    """Unit-norm rows [lo, hi) on a low-dimensional manifold, generated on the device chunk by chunk."""
+    out = torch.empty((hi - lo, d), dtype=torch.float32, device=dev)
+    for ci in range(lo // CHUNK, (hi + CHUNK - 1) // CHUNK):
+        c0, c1 = ci * CHUNK, (ci + 1) * CHUNK
+        a, b = max(lo, c0), min(hi, c1)
+        full = deep_chunk(params, ci, CHUNK, d, seed, dev)      # the whole chunk, so the stream does not depend on (lo, hi)
+        out[a - lo:b - lo] = full[a - c0:b - c0]
     return out
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--n", type=int, default=100_000_000)
-    ap.add_argument("--q", type=int, default=100_000)
+    ap.add_argument("--rows", "--n", dest="n", type=int, default=100_000_000)
+    ap.add_argument("--queries", "--q", dest="q", type=int, default=100_000)
     ap.add_argument("--dim", type=int, default=96)
     ap.add_argument("--hash-size", type=int, default=32)
     ap.add_argument("--k", type=int, default=10)
@@ -55,94 +74,125 @@ def main():
     ap.add_argument("--train-steps", type=int, default=5000)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--recall-queries", type=int, default=1000)
+    ap.add_argument("--shard", default="buckets", choices=["buckets", "rows"])
     args = ap.parse_args()
+    import torch.distributed as dist
     from nlsh_amd import training
     from nlsh_amd.data import SIFT
+    from nlsh_amd.distributed import ShardedIndexer, gather_and_merge, shard_range
     from nlsh_amd.encoders import MultiLayerRelu
     from nlsh_amd.hashings import MultivariateBernoulli
-    from nlsh_amd.indexer import Indexer
     from nlsh_amd.metrics import calculate_recall
+    from nlsh_amd.pipeline import QueryPipeline
 
-    dev = torch.device("cuda", 0)
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = 0 if os.environ.get("NLSH_BENCH_SAME_DEVICE") else int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        backend = os.environ.get("NLSH_BENCH_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     torch.manual_seed(0)
     N, Q, d, H, k, P = args.n, args.q, args.dim, args.hash_size, args.k, args.hash_times
+    params = _manifold_params(dev, d)
+    lo, hi = shard_range(N, rank, world)
     t0 = time.time()
-    corpus = deep_manifold_device(N, d, 1234, dev)
-    queries = deep_manifold_device(Q, d, 4321, dev)
+    corpus = deep_manifold_device(lo, hi, d, 1234, dev, params)          # this rank's row range only
+    queries = deep_manifold_device(0, Q, d, 4321, dev, params)           # replicated
     torch.cuda.synchronize()
     gen_s = time.time() - t0
-    print(f"[deep] generated {N} x {d} on device in {gen_s:.1f}s ({corpus.numel() * 4 / 1e9:.1f} GB)", flush=True)
+    if rank == 0:
+        print(f"[deep] rank 0 generated rows [{lo}, {hi}) x {d} on device in {gen_s:.1f}s ({corpus.numel() * 4 / 1e9:.1f} GB)", flush=True)
 
-    # learned hash on a sample (unit-norm rows: L2 ranking == cosine ranking; Deep1B is searched with L2)
-    sample = corpus[:: max(1, N // args.train_rows)][: args.train_rows].contiguous()
-    knn = training.self_knn(sample, 10)
+    # learned hash on a sample of rank 0's rows, broadcast (unit-norm rows: L2 ranking == cosine ranking; Deep1B uses L2)
     hashing = MultivariateBernoulli(MultiLayerRelu(d, [256, 256]), H, None, compat=H <= 16)
     t0 = time.time()
-    training.fit_triplet(hashing, sample, knn, n_steps=args.train_steps, margin=1.0, log=lambda s: None)
+    if rank == 0:
+        sample = corpus[:: max(1, (hi - lo) // args.train_rows)][: args.train_rows].contiguous()
+        knn = training.self_knn(sample, 10)
+        training.fit_triplet(hashing, sample, knn, n_steps=args.train_steps, margin=1.0, log=lambda s: None)
+        del knn, sample
+    if world > 1:
+        for p_ in hashing.parameters():
+            dist.broadcast(p_.data, src=0)
+    hashing.train_mode(False)
     train_s = time.time() - t0
-    del knn, sample
 
     torch.cuda.synchronize()
     t0 = time.time()
-    indexer = Indexer(hashing, corpus, SIFT.distance, compat=H <= 16)
+    sharded = ShardedIndexer(hashing, corpus, SIFT.distance, id_base=lo, shard=args.shard, compat=H <= 16)
+    indexer = sharded.local
+    if indexer._candidate_vectors_gpu is not corpus:
+        del corpus                                                       # the bucket partition owns its own copy of the rows
     torch.cuda.synchronize()
     build_s = time.time() - t0
     stats = indexer.bucket_stats()
-    print(f"[deep] index built in {build_s:.2f}s: {stats}", flush=True)
+    if rank == 0:
+        print(f"[deep] rank 0 index built in {build_s:.2f}s ({indexer._candidate_vectors_gpu.shape[0]} rows): {stats}", flush=True)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for a, b in ev:
         a.record(); b.record()
-    out = indexer.query_tensors(queries, k=k, hash_times=P, seed=1, check=True)   # sizes the task table
+    pipe = QueryPipeline(indexer, queries, k=k, hash_times=P, depth=3, want_keys=True,
+                         exchange=(lambda k64, nc: gather_and_merge(k64, nc, k)) if world > 1 else None)
+    pipe.submit(queries, seed=1)
+    pipe.synchronize()
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        out = indexer.query_tensors(queries, k=k, hash_times=P, seed=1, check=False, events=ev[i])
+        out = pipe.submit(queries, seed=1, events=ev[i])
+    pipe.synchronize()
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     elapsed = time.perf_counter() - t0
-    assert int(indexer.last_status.cpu()[1]) == 0
-    dist, idx, nc, _ = out
+    assert not pipe.overflowed()
+    dist_, idx, nc = out[:3]
     scan_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    sum_c_local = int(indexer.query_tensors(queries, k=k, hash_times=P, seed=1, check=False)[2].long().sum().item())
     sum_c = int(nc.long().sum().item())
 
-    # properties (size independent)
-    ok = idx >= 0
-    assert bool((dist[:, 1:] >= dist[:, :-1]).all()), "not ascending"
-    keys, nkeys = indexer.hash_device(queries, hash_times=P, seed=1)
-    valid = torch.arange(keys.shape[1], device=dev)[None, :] < nkeys[:, None]
-    ck = indexer.corpus_keys[idx.clamp(min=0).long()]
-    member = ((ck[:, :, None] == keys[:, None, :]) & valid[:, None, :]).any(-1)
-    assert bool((member | ~ok).all()), "a result is not in a probed bucket"
-    sel = slice(0, 2048)
-    ref = torch.nn.functional.pairwise_distance(queries[sel, None, :].expand(-1, k, -1).reshape(-1, d),
-                                                corpus[idx[sel].clamp(min=0).long().reshape(-1)]).reshape(-1, k)
-    assert bool(((dist[sel] - ref).abs() <= 2e-5 * ref.clamp(min=1.0))[ok[sel]].all()), "distance mismatch"
-
-    # recall on a sample (chunked brute force over the 100M rows)
-    R = min(args.recall_queries, Q)
-    qs = queries[:R]
-    best_d = torch.full((R, k), float("inf"), device=dev)
-    best_i = torch.full((R, k), -1, dtype=torch.int64, device=dev)
-    qq = (qs * qs).sum(1)[:, None]
-    for s in range(0, N, 1 << 22):
-        c = corpus[s:s + (1 << 22)]
-        dd = qq - 2.0 * (qs @ c.T) + (c * c).sum(1)[None, :]
-        td, ti = dd.topk(k, dim=1, largest=False)
-        cat_d, cat_i = torch.cat([best_d, td], 1), torch.cat([best_i, ti + s], 1)
-        o = cat_d.topk(k, dim=1, largest=False).indices
-        best_d, best_i = cat_d.gather(1, o), cat_i.gather(1, o)
-    recall = float(np.mean(calculate_recall(list(best_i.cpu().numpy()), [r[r >= 0].tolist() for r in idx[:R].cpu().numpy()])))
-
-    algo_bytes = 4.0 * d * sum_c
-    print(json.dumps({
-        "workload": f"configs[4] on ONE GPU: Deep100M-shaped, N={N} d={d} Q={Q} H={H} k={k} hash_times={P}",
-        "corpus_gb": N * d * 4 / 1e9, "generate_s": gen_s, "train_s": train_s, "index_build_s": build_s,
-        "n_buckets": stats["n_indexes"], "bucket_mean": stats["mean"], "bucket_max": stats["max"],
-        "queries_per_s": Q * args.steps / elapsed, "ms_per_step": 1e3 * elapsed / args.steps,
-        "scan_kernel": {0: "query-major", 1: "bucket-major", 2: "bucket-major LDS-tiled"}[indexer.last_algo],
-        "scan_ms": scan_ms, "mean_candidates_per_query": sum_c / Q, "algorithmic_GBps": algo_bytes / (scan_ms * 1e-3) / 1e9,
-        "recall_at_10_on_sample": recall, "recall_sample": R, "properties": "ascending, members of probed buckets, distances vs torch: ok",
-        "peak_mem_gb": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
+    if rank == 0:
+        # properties (size independent): ascending, distances of the returned ids (rows regenerated from their ids)
+        ok = idx >= 0
+        assert bool((dist_[:, 1:] >= dist_[:, :-1]).all()), "not ascending"
+        sel = idx[:256].clamp(min=0).long().reshape(-1)
+        rows = torch.empty((sel.numel(), d), dtype=torch.float32, device=dev)
+        for ci in torch.unique(sel // CHUNK).tolist():
+            m = (sel // CHUNK) == ci
+            rows[m] = deep_chunk(params, ci, CHUNK, d, 1234, dev)[sel[m] - ci * CHUNK]
+        ref = torch.nn.functional.pairwise_distance(queries[:256, None, :].expand(-1, k, -1).reshape(-1, d), rows).reshape(-1, k)
+        assert bool(((dist_[:256] - ref).abs() <= 2e-5 * ref.clamp(min=1.0))[ok[:256]].all()), "distance mismatch"
+        # recall on a sample (chunked brute force over all N rows, regenerated chunk by chunk)
+        R = min(args.recall_queries, Q)
+        qs = queries[:R]
+        best_d = torch.full((R, k), float("inf"), device=dev)
+        best_i = torch.full((R, k), -1, dtype=torch.int64, device=dev)
+        qq = (qs * qs).sum(1)[:, None]
+        for ci in range((N + CHUNK - 1) // CHUNK):
+            c = deep_chunk(params, ci, CHUNK, d, 1234, dev)[: min(CHUNK, N - ci * CHUNK)]
+            dd = qq - 2.0 * (qs @ c.T) + (c * c).sum(1)[None, :]
+            td, ti = dd.topk(k, dim=1, largest=False)
+            cat_d, cat_i = torch.cat([best_d, td], 1), torch.cat([best_i, ti + ci * CHUNK], 1)
+            o = cat_d.topk(k, dim=1, largest=False).indices
+            best_d, best_i = cat_d.gather(1, o), cat_i.gather(1, o)
+        recall = float(np.mean(calculate_recall(list(best_i.cpu().numpy()), [r[r >= 0].tolist() for r in idx[:R].cpu().numpy()])))
+        print(json.dumps({
+            "workload": f"configs[4]: Deep100M-shaped, N={N} d={d} Q={Q} H={H} k={k} hash_times={P}, {world} rank(s), corpus {args.shard} sharded",
+            "corpus_gb": N * d * 4 / 1e9, "generate_s": gen_s, "train_s": train_s, "index_build_s": build_s,
+            "rank0_rows": int(indexer._candidate_vectors_gpu.shape[0]), "rank0_buckets": stats["n_indexes"], "bucket_mean": stats["mean"],
+            "bucket_max": stats["max"], "queries_per_s": Q * args.steps / elapsed, "ms_per_step": 1e3 * elapsed / args.steps,
+            "step_driver": "three-stage pipeline",
+            "scan_kernel": {0: "query-major", 1: "bucket-major", 2: "bucket-major LDS-tiled"}[pipe.algo],
+            "rank0_scan_ms": scan_ms, "mean_candidates_per_query": sum_c / Q,
+            "rank0_algorithmic_GBps": 4.0 * d * sum_c_local / (scan_ms * 1e-3) / 1e9,
+            "recall_at_10_on_sample": recall, "recall_sample": R, "properties": "ascending, distances vs torch on regenerated rows: ok",
+            "rank0_peak_mem_gb": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
