@@ -42,6 +42,10 @@ extern "C" int nlsh_debug_scan_trace(float *host, int n_floats) {
 #define NLSH_TILED_KB 4
 #endif
 
+#ifndef NLSH_FAT_STAGES
+#define NLSH_FAT_STAGES 1
+#endif
+
 #ifndef NLSH_ABLATE
 #define NLSH_ABLATE 0  // diagnostic timing builds only: 1 no distance math, 2 no global loads, 3 no top-k, 4 no scalar loads
 #endif
@@ -468,16 +472,24 @@ __global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
     const float4 *corpus4 = reinterpret_cast<const float4 *>(a.corpus);
     const long long stride4 = a.row_stride >> 2;
     const int d4 = a.d4p;
-    const int nkb = (d4 + KB - 1) / KB;
     const int ntile = (nrows + 63) >> 6;
-    // staging map: KB threads cover 16*KB contiguous bytes of a row
-    const int sc = tid % KB, sr = tid / KB;
+    // A task costs ~15 us before it does any work (r01 trace: 16 us for 1 query x <= 64 rows, 55 us for 16 x 256): one
+    // exposed global-load round trip + two barriers per k-block.  Short segments therefore take FATTER k-blocks --
+    // the LDS tile holds 64*TPS rows x KB chunks = 64 rows x TPS*KB chunks: 1 tile -> 4*KB chunks per stage, 2 tiles ->
+    // 2*KB -- and go through a quarter / half of the stages (a third of the tasks of the headline run are <= 128 rows).
+    const int kshift = NLSH_FAT_STAGES ? (ntile <= 1 ? 2 : (ntile == 2 ? 1 : 0)) : 0;
+    const int KBt = KB << kshift;            // chunks per k-block of THIS task
+    const int RSt = KBt + 1;                 // odd row stride of its tile
+    const int RPPt = RPP >> kshift;          // rows covered by one pass of the workgroup
+    const int nkb = (d4 + KBt - 1) / KBt;
+    // staging map: KBt threads cover 16*KBt contiguous bytes of a row
+    const int sc = tid & (KBt - 1), sr = tid / KBt;
     float4 stg[SPT];
     auto stage_load = [&](int kb) {
-        const int gc = kb * KB + sc;
+        const int gc = kb * KBt + sc;
 #pragma unroll
         for (int i = 0; i < SPT; ++i) {
-            const int r = sr + RPP * i;
+            const int r = sr + RPPt * i;
             stg[i] = (NLSH_ABLATE != 2 && r < nrows && gc < d4) ? corpus4[(long long)(row0 + r) * stride4 + gc] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
@@ -493,17 +505,17 @@ __global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
         const unsigned long long ta = SCAN_NOW();
         __syncthreads();  // everyone has finished reading the previous k-block
 #pragma unroll
-        for (int i = 0; i < SPT; ++i) tile[(sr + RPP * i) * RS + sc] = stg[i];
+        for (int i = 0; i < SPT; ++i) tile[(sr + RPPt * i) * RSt + sc] = stg[i];
         __syncthreads();
         if (kb + 1 < nkb) stage_load(kb + 1);  // in flight while this k-block is computed
         const unsigned long long tb = SCAN_NOW();
         ts_stage += tb - ta;
         if (NLSH_ABLATE != 1 && nqw > 0) {
-            const int nchunk = min(KB, d4 - kb * KB);
+            const int nchunk = min(KBt, d4 - kb * KBt);
             const_f32p qk[QW];
 #pragma unroll
-            for (int jq = 0; jq < QW; ++jq) qk[jq] = qs[jq] + kb * KB * 4;
-            const float4 *col = tile + lane * RS;
+            for (int jq = 0; jq < QW; ++jq) qk[jq] = qs[jq] + kb * KBt * 4;
+            const float4 *col = tile + lane * RSt;
             QChunk<QW> qa, qb;
             load_qchunk<QW, false>(qa, qk, nqw, 0);
             for (int c = 0; c < nchunk; c += 2) {
@@ -511,12 +523,12 @@ __global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
                 load_qchunk<QW, false>(qb, qk, nqw, has1 ? c + 1 : c);
 #pragma unroll
                 for (int tl = 0; tl < TPS; ++tl)
-                    if (tl < ntile) apply_qchunk<METRIC, QW, false>(qa, col[tl * 64 * RS + c], nqw, acc[tl]);
+                    if (tl < ntile) apply_qchunk<METRIC, QW, false>(qa, col[tl * 64 * RSt + c], nqw, acc[tl]);
                 if (!has1) break;
                 load_qchunk<QW, false>(qa, qk, nqw, c + 2 < nchunk ? c + 2 : c);
 #pragma unroll
                 for (int tl = 0; tl < TPS; ++tl)
-                    if (tl < ntile) apply_qchunk<METRIC, QW, false>(qb, col[tl * 64 * RS + c + 1], nqw, acc[tl]);
+                    if (tl < ntile) apply_qchunk<METRIC, QW, false>(qb, col[tl * 64 * RSt + c + 1], nqw, acc[tl]);
             }
         }
 #ifdef NLSH_SCAN_TRACE

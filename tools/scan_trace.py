@@ -54,3 +54,16 @@ print(f"kernel span {span / 100:.1f} us; workgroups in flight per 10 us slice (1
 print(" ".join(f"{int(v)}" for v in busy))
 order = np.argsort(start)
 print("first/last task start (us):", start[order[0]] / 100, start[order[-1]] / 100, " last end:", end.max() / 100)
+# who uses the workgroup time: share of the summed task time by task shape
+tot = buf[:, 0].sum()
+print("share of summed workgroup time / of tasks, by (queries, rows) of the task:")
+for qlo, qhi in ((1, 1), (2, 4), (5, 8), (9, 15), (16, 16)):
+    for rlo, rhi in ((1, 64), (65, 128), (129, 255), (256, 256)):
+        m = (buf[:, 6] >= qlo) & (buf[:, 6] <= qhi) & (buf[:, 7] >= rlo) & (buf[:, 7] <= rhi)
+        if m.any():
+            print(f"  nq {qlo:2d}-{qhi:2d} rows {rlo:3d}-{rhi:3d}: time {buf[m, 0].sum() / tot:6.3f}  tasks {m.mean():6.3f}  mean {buf[m, 0].mean() / 100:6.1f} us")
+small = buf[(buf[:, 6] <= 4) & (buf[:, 7] <= 64)]
+print(f"small tasks (<= 4 queries x <= 64 rows): {len(small)}")
+for i, nm in enumerate(names[:6]):
+    if i != 4:
+        print(f"  {nm:28s} mean {small[:, i].mean():9.1f}")
