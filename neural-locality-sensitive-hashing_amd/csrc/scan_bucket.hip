@@ -369,7 +369,8 @@ __global__ __launch_bounds__(256) void bscan2_kernel(BArgs a) {
 // VGPRs, 3-4 waves/SIMD, 0.43-0.49 ms); reading the next step's row chunk one step ahead (+3 %); reading all
 // tiles' chunks of a step up front (+-0); a second copy of the loop without the per-query guards for waves that
 // hold all QW queries (79 VGPRs -> 6 waves/SIMD: 0.363 vs 0.344 ms); requesting a k-block's first query chunk before
-// the stage barriers (0.346 vs 0.337 ms: the barrier's lgkmcnt(0) then also waits for the scalar loads).
+// the stage barriers (0.346 vs 0.337 ms: the barrier's lgkmcnt(0) then also waits for the scalar loads); touching the
+// next 64-byte query line with a dummy scalar load one line ahead (SGPR spills 28 -> 50: 0.355 vs 0.331 ms).
 typedef const __attribute__((address_space(4))) float *const_f32p;
 
 __global__ __launch_bounds__(64) void bprep_kernel(BArgs a, int metric) {
