@@ -19,6 +19,8 @@ scans its own shard, and the only exchange step is ONE all-gather (RCCL over xGM
 "nccl") of the per-rank `[Q, k]` 64-bit (distance,id) keys + `[Q]` candidate counts, followed by the same
 (distance, id) merge the single-GPU path uses -> results identical to one GPU.
 """
+import os
+import warnings
 from typing import Callable, Optional, Tuple
 
 import torch
@@ -138,14 +140,26 @@ def exchange_rows_by_bucket(local_rows: torch.Tensor, local_keys: torch.Tensor, 
     lo = _all_gather_rows(torch.tensor([local_rows.shape[0]], dtype=torch.int64, device=local_keys.device), group)
     start = int(lo[:rank].sum().item())
     owner_all, stats = plan_bucket_shards(keys_all, world)
-    dest = owner_all[start:start + local_rows.shape[0]]
-    order = torch.argsort(dest, stable=True)                       # keeps ascending row order per destination
-    send_counts = torch.bincount(dest, minlength=world)
-    counts_all = _all_gather_rows(send_counts.view(1, world), group)      # [G, G]: row r = what rank r sends
-    recv_counts = counts_all[:, rank].cpu().tolist()
-    send_counts = send_counts.cpu().tolist()
-    rows = _all_to_all_rows(local_rows[order], send_counts, recv_counts, group)
-    ids = _all_to_all_rows((order + id_base).to(torch.int32), send_counts, recv_counts, group)
+    n_local = local_rows.shape[0]
+    ids_local = torch.arange(n_local, device=local_rows.device, dtype=torch.int32) + int(id_base)
+    if os.environ.get("NLSH_SHARD_EXCHANGE", "alltoall") == "alltoall":
+        try:
+            dest = owner_all[start:start + n_local]
+            order = torch.argsort(dest, stable=True)                   # keeps ascending row order per destination
+            send_counts = torch.bincount(dest, minlength=world)
+            counts_all = _all_gather_rows(send_counts.view(1, world), group)  # [G, G]: row r = what rank r sends
+            recv_counts = counts_all[:, rank].cpu().tolist()
+            send_counts = send_counts.cpu().tolist()
+            rows = _all_to_all_rows(local_rows[order], send_counts, recv_counts, group)
+            ids = _all_to_all_rows(ids_local[order], send_counts, recv_counts, group)
+            return rows, ids, stats
+        except (RuntimeError, NotImplementedError) as e:     # a backend without all_to_all_single: same result, more traffic
+            warnings.warn(f"all_to_all_single unavailable ({e}); falling back to an all-gather of the rows")
+    # fallback (NLSH_SHARD_EXCHANGE=allgather): every rank gathers all rows and keeps the ones it owns -- G times the
+    # traffic of the all-to-all, the same rows in the same (ascending global id) order
+    mine = torch.nonzero(owner_all == rank).view(-1)
+    rows = _all_gather_rows(local_rows, group)[mine]
+    ids = _all_gather_rows(ids_local, group)[mine]
     return rows, ids, stats
 
 

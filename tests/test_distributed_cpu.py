@@ -94,11 +94,12 @@ def test_two_rank_gloo_merge_equals_single_shard(tmp_path):
 
 
 # ----------------------------------------------------------------------------- bucket partition (build-time exchange)
-def _exchange_worker(rank, world, port, out_dir):
+def _exchange_worker(rank, world, port, out_dir, mode="alltoall"):
     for p in (ROOT, os.path.join(ROOT, "neural-locality-sensitive-hashing_amd")):
         sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["NLSH_SHARD_EXCHANGE"] = mode
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from nlsh_amd.distributed import exchange_rows_by_bucket, shard_range
     keys_all, rows_all = _exchange_case()
@@ -117,9 +118,9 @@ def _exchange_case():
     return keys, rows
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_gloo_bucket_exchange_moves_every_bucket_whole(tmp_path, world):
-    mp.spawn(_exchange_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("world,mode", [(2, "alltoall"), (3, "alltoall"), (2, "allgather")])
+def test_gloo_bucket_exchange_moves_every_bucket_whole(tmp_path, world, mode):
+    mp.spawn(_exchange_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
     from nlsh_amd.distributed import assign_buckets, corpus_statistics
     keys_all, rows_all = _exchange_case()
     parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
