@@ -370,7 +370,8 @@ __global__ __launch_bounds__(256) void bscan2_kernel(BArgs a) {
 // tiles' chunks of a step up front (+-0); a second copy of the loop without the per-query guards for waves that
 // hold all QW queries (79 VGPRs -> 6 waves/SIMD: 0.363 vs 0.344 ms); requesting a k-block's first query chunk before
 // the stage barriers (0.346 vs 0.337 ms: the barrier's lgkmcnt(0) then also waits for the scalar loads); touching the
-// next 64-byte query line with a dummy scalar load one line ahead (SGPR spills 28 -> 50: 0.355 vs 0.331 ms).
+// next 64-byte query line with a dummy scalar load one line ahead (SGPR spills 28 -> 50: 0.355 vs 0.331 ms); one
+// s_load_dwordx16 per query line instead of four x4 (64 VGPRs kept, +-0: the scalar loads are not what waves wait for).
 typedef const __attribute__((address_space(4))) float *const_f32p;
 
 __global__ __launch_bounds__(64) void bprep_kernel(BArgs a, int metric) {
