@@ -104,6 +104,7 @@ class Indexer:
         self.row_ids = row_ids
         self._index2row = None
         self._perm_host = None
+        self._e_sb = None
         self._ws = {}               # scan workspace per stream (concurrent query batches on different HIP streams)
         self._max_tasks = {}
         self._build_index()
@@ -181,9 +182,11 @@ class Indexer:
 
     # ------------------------------------------------------------------ query
     def _size_biased_bucket(self):
-        s = self.bucket_sizes.astype(np.float64)
-        n = max(float(s.sum()), 1.0)
-        return float((s * s).sum() / n) if len(s) else 0.0            # expected size of the bucket a point lands in
+        if self._e_sb is None:                                       # static per index; every batch asks for it
+            s = self.bucket_sizes.astype(np.float64)
+            n = max(float(s.sum()), 1.0)
+            self._e_sb = float((s * s).sum() / n) if len(s) else 0.0  # expected size of the bucket a point lands in
+        return self._e_sb
 
     def choose_algo(self, Q, P):
         """Bucket-major pays when a corpus row is a candidate of several queries of the batch
