@@ -147,6 +147,19 @@ class MultivariateBernoulli:
         self._packed, self._packed_sig, self._keep = packed, sig, stack
         return packed
 
+    def encode_args(self, n, keys, nkeys):
+        """Fixed part of an `nlsh_encode_hash` call that fills a caller-owned key table (weights as they are NOW):
+        (n_layers, dims array, packed weights ptr, act, key_mode, n_probes) and the output pointers, as plain values
+        for callers that launch many batches (nlsh_amd/pipeline.py)."""
+        dims = self.dims()
+        self._dims_arr = _capi.int_array(dims)
+        packed = self.packed_weights()
+        return ((len(dims) - 1, self._dims_arr, packed.data_ptr(), _capi.ACT_TANH if self._tanh_output else _capi.ACT_SIGMOID,
+                 self.key_mode, n), (None, None, None, keys.data_ptr(), nkeys.data_ptr()))
+
+    def next_seed(self):
+        return (self._seed + 0x9E3779B97F4A7C15 * (next(self._calls) + 1)) & 0xFFFFFFFFFFFFFFFF
+
     def _run(self, x, n, n_multi_rows=None, seed=None, row0=0, want_probs=False, z_out=None, code_out=None, out=None):
         if x.device.type != "cuda":
             raise _capi.NlshHipError(_capi.E_INVALID, "encode_hash needs a device tensor; there is no CPU path")

@@ -266,17 +266,25 @@ class Indexer:
         self.last_algo = algo
         return out_dist, out_idx, ncand, out_keys
 
-    def _scan_launch(self, q, keys, nkeys, k, algo, max_tasks, out_dist, out_idx, out_keys, ncand, status, ws, phases, events=None):
-        """One `nlsh_scan_topk_phase` call on the current stream with caller-owned buffers (PLAN, SCAN or both)."""
-        Q, d = q.shape
+    def _scan_args(self, Q, d, keys, nkeys, k, algo, max_tasks, out_dist, out_idx, out_keys, ncand, status, ws):
+        """The arguments of `nlsh_scan_topk_phase` that do not change between batches of one shape, as plain ints:
+        (everything before `queries`, everything between `q_stride`/`Q` and the events).  Callers that launch many
+        batches (nlsh_amd/pipeline.py) build them once per buffer set; a call is then one ctypes transition."""
+        a = lambda t: None if t is None else t.data_ptr()   # noqa: E731
         metric = _capi.METRIC_L2_EPS if self.metric == "l2" else _capi.METRIC_COSINE
+        pre = (a(self.corpus_sorted), self.row_stride, d, a(self.gid), a(self.uniq_keys), a(self.offsets), a(self.bucket_order),
+               self.n_buckets, a(self.inv_norm))
+        post = (Q, a(keys), a(nkeys), keys.shape[1], k, metric, algo, self.seg_rows or 512, a(out_dist), a(out_idx), a(out_keys),
+                a(ncand), a(status), a(ws), ws.numel(), max_tasks)
+        return pre, post
+
+    def _scan_launch(self, q, keys, nkeys, k, algo, max_tasks, out_dist, out_idx, out_keys, ncand, status, ws, phases, events=None):
+        """One `nlsh_scan_topk_phase` call on the current stream with caller-owned buffers (any subset of the phases)."""
+        Q, d = q.shape
+        pre, post = self._scan_args(Q, d, keys, nkeys, k, algo, max_tasks, out_dist, out_idx, out_keys, ncand, status, ws)
         _capi.check(_capi.lib().nlsh_scan_topk_phase(
-            _capi.ptr(self.corpus_sorted), self.row_stride, d, _capi.ptr(self.gid), _capi.ptr(self.uniq_keys),
-            _capi.ptr(self.offsets), _capi.ptr(self.bucket_order), self.n_buckets, _capi.ptr(self.inv_norm), _capi.ptr(q),
-            q.stride(0) if Q else d, Q, _capi.ptr(keys), _capi.ptr(nkeys), keys.shape[1], k, metric, algo, self.seg_rows or 512,
-            _capi.ptr(out_dist), _capi.ptr(out_idx), _capi.ptr(out_keys), _capi.ptr(ncand), _capi.ptr(status), _capi.ptr(ws),
-            ws.numel(), max_tasks, events[0].cuda_event if events else None, events[1].cuda_event if events else None,
-            _stream(q.device), phases))
+            *pre, q.data_ptr(), q.stride(0) if Q else d, *post,
+            events[0].cuda_event if events else None, events[1].cuda_event if events else None, _stream(q.device), phases))
 
     def _scan_sliced(self, q, keys, nkeys, k, want_keys, check):
         """hash_times > 64 (eval.py:148 sweeps n_samples up to 100): the key table is scanned in column slices of

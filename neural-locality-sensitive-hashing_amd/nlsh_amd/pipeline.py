@@ -68,39 +68,52 @@ class QueryPipeline:
             s.ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
             s.planned, s.scanned, s.done = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
             s.done.record(torch.cuda.current_stream(dev))
+            # everything about the slot's launches that does not change from batch to batch, as plain ints: a submit is
+            # four ctypes transitions + six event calls (built per call it cost 125 us of host time per batch, which
+            # is what bounded the pipeline on small shards)
+            s.scan_pre, s.scan_post = indexer._scan_args(self.Q, self.d, s.keys, s.nkeys, k, self.algo, self.max_tasks, s.out_dist,
+                                                         s.out_idx, s.out_keys, s.ncand, s.status, s.ws)
+            s.enc_pre, s.enc_post = indexer._hashing.encode_args(self.P, s.keys, s.nkeys)
             self.slots.append(s)
+        self._lib = _capi.lib()
+        self._n_multi = indexer._n_multi_rows(self.Q)
         self.n_submitted = 0
         self.last_slot = None
-
-    def _launch(self, queries, s, phases, events=None):
-        self.indexer._scan_launch(queries, s.keys, s.nkeys, self.k, self.algo, self.max_tasks, s.out_dist, s.out_idx,
-                                  s.out_keys, s.ncand, s.status, s.ws, phases, events)
 
     def submit(self, queries, seed=None, events=None):
         """Enqueue one batch; returns (dist, idx, ncand, keys64 | None) -- device tensors owned by the batch's slot
         (or fresh ones from `exchange`), valid once the tail stream has passed the batch (`synchronize()`), and
-        overwritten `depth` submits later.  `events`: (begin, end) pair recorded around the scan kernel."""
+        overwritten `depth` submits later.  `events`: (begin, end) pair recorded around the scan kernel.
+        The hasher's weights are the ones present when the pipeline was built."""
         if queries.shape != (self.Q, self.d) or queries.dtype != torch.float32 or queries.stride(1) != 1:
             raise ValueError("batch shape/dtype differs from the pipeline's sample batch")
+        ix, L = self.indexer, self._lib
         s = self.slots[self.n_submitted % len(self.slots)]
         self.n_submitted += 1
-        self.front.wait_stream(torch.cuda.current_stream(queries.device))   # the batch may still be in flight there
-        self.front.wait_event(s.done)                                       # the slot's previous batch has left the tail
-        with torch.cuda.stream(self.front):
-            self.indexer.hash_device(queries, hash_times=self.P, seed=seed, out=(s.keys, s.nkeys))
-            self._launch(queries, s, _capi.PHASE_PLAN)
-            s.planned.record(self.front)
-        self.mid.wait_event(s.planned)
-        with torch.cuda.stream(self.mid):
-            self._launch(queries, s, _capi.PHASE_SCAN, events)
-            s.scanned.record(self.mid)
-        self.tail.wait_event(s.scanned)
-        with torch.cuda.stream(self.tail):
-            self._launch(queries, s, _capi.PHASE_MERGE)
-            out = (s.out_dist, s.out_idx, s.ncand, s.out_keys)
-            if self.exchange is not None:
+        front, mid, tail = self.front, self.mid, self.tail
+        front.wait_stream(torch.cuda.current_stream(queries.device))        # the batch may still be in flight there
+        front.wait_event(s.done)                                            # the slot's previous batch has left the tail
+        qp, qs = queries.data_ptr(), queries.stride(0)
+        if seed is None:
+            seed = ix._hashing.next_seed()
+        rc = L.nlsh_encode_hash(qp, self.Q, qs, *s.enc_pre, self._n_multi, seed, 0, *s.enc_post, front.cuda_stream)
+        if rc == 0:
+            rc = L.nlsh_scan_topk_phase(*s.scan_pre, qp, qs, *s.scan_post, None, None, front.cuda_stream, _capi.PHASE_PLAN)
+        s.planned.record(front)
+        mid.wait_event(s.planned)
+        if rc == 0:
+            rc = L.nlsh_scan_topk_phase(*s.scan_pre, qp, qs, *s.scan_post, events[0].cuda_event if events else None,
+                                        events[1].cuda_event if events else None, mid.cuda_stream, _capi.PHASE_SCAN)
+        s.scanned.record(mid)
+        tail.wait_event(s.scanned)
+        if rc == 0:
+            rc = L.nlsh_scan_topk_phase(*s.scan_pre, qp, qs, *s.scan_post, None, None, tail.cuda_stream, _capi.PHASE_MERGE)
+        _capi.check(rc)
+        out = (s.out_dist, s.out_idx, s.ncand, s.out_keys)
+        if self.exchange is not None:
+            with torch.cuda.stream(tail):
                 out = tuple(self.exchange(s.out_keys, s.ncand)) + (None,)
-            s.done.record(self.tail)
+        s.done.record(tail)
         self.last_slot = s
         return out
 

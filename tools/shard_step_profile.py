@@ -71,10 +71,11 @@ def main():
             pipe.submit(queries, seed=100 + i, events=ev[i])
         else:
             indexer.query_tensors(queries, k=10, hash_times=10, seed=100 + i, want_keys=True, check=False, events=ev[i])
+    enqueue_ms = 1e3 * (time.perf_counter() - t0) / args.steps      # host time to enqueue a step (the GPU runs behind)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     print(json.dumps({"world": args.world, "rank": args.rank, "shard": args.shard, "pipeline": bool(args.pipeline), "rows": hi - lo, "algo": indexer.last_algo,
-                      "local_step_ms": 1e3 * el / args.steps, "scan_ms": float(np.mean([a.elapsed_time(b) for a, b in ev]))}))
+                      "local_step_ms": 1e3 * el / args.steps, "host_enqueue_ms": enqueue_ms, "scan_ms": float(np.mean([a.elapsed_time(b) for a, b in ev]))}))
 
 
 if __name__ == "__main__":
