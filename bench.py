@@ -91,7 +91,7 @@ def main():
 
     from nlsh_amd import _capi, synth
     from nlsh_amd.data import Glove, SIFT, brute_force_topk
-    from nlsh_amd.distributed import ShardedIndexer, gather_and_merge, shard_range
+    from nlsh_amd.distributed import ShardedIndexer, TopkExchange, gather_and_merge, shard_range
     from nlsh_amd.encoders import MultiLayerRelu
     from nlsh_amd.hashings import MultivariateBernoulli
     from nlsh_amd.indexer import Indexer
@@ -166,11 +166,13 @@ def main():
     step(-1, check=True)  # sizes the segment table (may retry once); untimed
     pipe, cur = None, [None]
 
-    def exchange(k64, nc):   # back stage of the pipeline on a sharded index: all-gather of per-shard top-k + merge
+    xchg = TopkExchange(k) if world > 1 else None
+
+    def exchange(k64, nc):   # tail stage of the pipeline on a sharded index: all-gather of per-shard top-k + merge
         i = cur[0]
         if i is not None:
             ev_x[i][0].record()
-        out_ = gather_and_merge(k64, nc, k)
+        out_ = xchg(k64, nc)
         if i is not None:
             ev_x[i][1].record()
         return out_

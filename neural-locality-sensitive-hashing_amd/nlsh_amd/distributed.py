@@ -68,6 +68,41 @@ def gather_and_merge(local_keys: torch.Tensor, local_ncand: torch.Tensor, k: int
     return merge_fn(packed_all.view(world, Q, k + 1), k)
 
 
+class TopkExchange:
+    """`gather_and_merge` for a caller that runs it every batch (nlsh_amd/pipeline.py's tail stage): the packed send row,
+    the gathered table and the merged outputs are allocated once per distinct key table (one per pipeline slot) instead
+    of per call, so the host side of the exchange is two small copies, one collective and one ctypes transition.
+    The returned tensors are overwritten when the same key table comes round again."""
+
+    def __init__(self, k: int, group=None):
+        self.k, self.group, self.world = k, group, dist.get_world_size(group)
+        self._bufs = {}
+
+    def __call__(self, keys64: torch.Tensor, ncand: torch.Tensor):
+        if keys64.device.type != "cuda":
+            raise _capi.NlshHipError(_capi.E_INVALID, "merge_topk needs device tensors; there is no CPU path")
+        k, world = self.k, self.world
+        Q, dev = keys64.shape[0], keys64.device
+        b = self._bufs.get(keys64.data_ptr())
+        if b is None:
+            b = self._bufs[keys64.data_ptr()] = (
+                torch.empty((Q, k + 1), dtype=torch.int64, device=dev), torch.empty((world * Q, k + 1), dtype=torch.int64, device=dev),
+                torch.empty((Q, k), dtype=torch.float32, device=dev), torch.empty((Q, k), dtype=torch.int32, device=dev),
+                torch.empty((Q,), dtype=torch.int32, device=dev))
+        packed, packed_all, out_dist, out_idx, out_nc = b
+        packed[:, :k].copy_(keys64)
+        packed[:, k].copy_(ncand)
+        if _staged(packed, self.group):     # gloo rehearsal on device tensors
+            host = torch.empty(packed_all.shape, dtype=packed_all.dtype)
+            dist.all_gather_into_tensor(host, packed.cpu(), group=self.group)
+            packed_all.copy_(host)
+        else:
+            dist.all_gather_into_tensor(packed_all, packed, group=self.group)
+        _capi.check(_capi.lib().nlsh_merge_topk(packed_all.data_ptr(), k + 1, world, Q, k, None, out_dist.data_ptr(), out_idx.data_ptr(),
+                                                out_nc.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+        return out_dist, out_idx, out_nc
+
+
 # ----------------------------------------------------------------------------- bucket partition
 def assign_buckets(counts: torch.Tensor, world: int) -> torch.Tensor:
     """Owner rank of every bucket, given the bucket sizes in ascending-key order (int64 [nb]).

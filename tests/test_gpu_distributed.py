@@ -43,7 +43,7 @@ def _worker(rank, world, port, shard, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     corpus, batches, Ws, bs, d, H = _case()
     from nlsh_amd.data import SIFT
-    from nlsh_amd.distributed import ShardedIndexer, gather_and_merge, shard_range
+    from nlsh_amd.distributed import ShardedIndexer, TopkExchange, shard_range
     from nlsh_amd.pipeline import QueryPipeline
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -52,7 +52,7 @@ def _worker(rank, world, port, shard, out_dir):
     k, P = 10, 6
     qd = [torch.from_numpy(b).to(dev) for b in batches]
     direct = [tuple(t.cpu().numpy() for t in sharded.query_tensors(b, k=k, hash_times=P, seed=70 + i)) for i, b in enumerate(qd)]
-    pipe = QueryPipeline(sharded.local, qd[0], k=k, hash_times=P, depth=3, exchange=lambda k64, nc: gather_and_merge(k64, nc, k))
+    pipe = QueryPipeline(sharded.local, qd[0], k=k, hash_times=P, depth=3, exchange=TopkExchange(k))
     piped = []
     for i, b in enumerate(qd):
         out = pipe.submit(b, seed=70 + i)
