@@ -4,27 +4,41 @@
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" = one pass of the hot path over the whole query batch (BASELINE.json configs[1]:
-SIFT1M-shaped, 1M x 128-d corpus, 10k queries, 16-bit hash, k=10, hash_times=10):
-encode_hash (MLP on fp32 MFMA + bits + multi-probe keys) -> plan -> scan_topk -> merge, all
-device-resident (inputs in HBM before the timed region, results left in HBM).  At N=1 every kernel of a step runs
-back to back on one stream (each kernel alone on the chip: undisturbed roofline timings).  At N>1 the K timed steps run
-as a three-stage pipeline over three HIP streams (nlsh_amd/pipeline.py): encode + plan of batch i+1 and merge +
-all-gather of batch i-1 beside the scan of batch i -- every kernel of every step runs inside the timed region, scan
-kernels never overlap each other, results are bit-identical to sequential calls (`--pipeline on|off` forces either).
-N>1: corpus buckets sharded over the ranks (whole buckets per rank, one build-time all-to-all; `--shard rows` keeps
-contiguous row ranges instead), every rank answers all queries over its shard, one all-gather (RCCL) of
-the per-rank top-k + merge per step ("strong" scaling: total work fixed).
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (a torchrun child
+process, before this process touches the GPU) and exits with its code; a WORLD_SIZE that disagrees with --gpus is an
+error, never a silent 1-GPU run.
 
-Prints ONE JSON line (rank 0).  `roofline` is the scan kernel's algorithmic bytes (4*d*sum C_q,
-SURVEY.md §8(d)) over its HIP-event-measured duration; `cpu_baseline` is the CPU oracle timed on
-this box's host cores on a bounded sample of the same queries and candidate sets.
-There is no dataset or reference checkpoint offline: data is seeded synthetic (`synth.sift_manifold`)
-and the hash is the one our minimal trainer learned on it (checkpoints/, see config.hash).
+Workload = BASELINE.json configs[1]: SIFT1M-shaped, 1M x 128-d corpus, 10k queries per batch, 16-bit learned hash,
+k=10, hash_times=10.  A "step" = ONE `Indexer.query(batch, k=10, hash_times=10)` call -- the reference's QPS protocol
+(nlsh/trainers/base.py:93-96,107-108): queries already in HBM, index built, hashing included, and
+the call returns the reference's Python lists (so it ends with the device->host copy of the ids).  K such calls are
+timed between barrier + synchronize pairs, rotating over `--batches` different query batches:
+    value        = Q * K / elapsed            (whole job, max over ranks)
+    ms_per_step  = elapsed / K
+The same hot path with results LEFT IN HBM (`query_tensors`: encode_hash -> plan -> scan -> merge, what a serving
+pipeline that consumes device tensors sees) is timed in a second K-step region and reported as the top-level fields
+`device_resident_qps` / `device_resident_ms_per_step`; its scan kernel is bracketed by HIP events on the launch
+stream, which is where `roofline` comes from.  At N=1 the kernels of a device-resident step run back to back on one
+stream (each kernel alone on the chip); at N>1 they go through the three-stage pipeline of nlsh_amd/pipeline.py with
+the all-gather in its tail stage (`--pipeline on|off` forces either).
+N>1: corpus buckets sharded over the ranks (whole buckets per rank, one build-time all-to-all; `--shard rows` keeps
+contiguous row ranges), every rank answers all queries over its shard, one all-gather (RCCL) of the per-rank top-k +
+merge per step ("strong" scaling: total work fixed).
+
+`roofline`: the tiled / wave-level bucket-major schedules fetch a corpus row once per query GROUP, so they are bound by
+fp32 VALU issue, not HBM: bound = "valu", achieved = 3*d*sum(C_q) flop / kernel time against the 157.3 TF fp32 vector
+peak.  The query-major schedule re-reads every row per query: bound = "hbm", achieved = 4*d*sum(C_q) B / kernel time
+against 8 TB/s.  The algorithmic-bytes rate is always reported as `algorithmic_GBps` (not a fraction of anything for
+the bucket-major schedules).  `cpu_baseline` = the CPU restatements timed on this box's host cores on a bounded sample.
+There is no dataset or reference checkpoint offline: data is seeded synthetic (`synth.sift_manifold`) and the hash is
+the one our minimal trainer learned on it (checkpoints/, see config.hash).
 """
 import argparse
+import copy
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -39,9 +53,11 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (155 TF measured)
+VALU_F32_PEAK_TFLOPS = 157.3  # same figure: 1024 SIMDs x 2.4 GHz x 64 lanes x 2 flop / 2 cycles per wave64 v_fma_f32
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_r02.json")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -50,6 +66,7 @@ def parse():
                     help="sift1m = BASELINE.json configs[1] (headline); glove = configs[2] (1,183,514 x 100-d, cosine, 24-bit)")
     ap.add_argument("--n", type=int, default=int(os.environ.get("NLSH_BENCH_N", 0)))
     ap.add_argument("--q", type=int, default=int(os.environ.get("NLSH_BENCH_Q", 10_000)))
+    ap.add_argument("--batches", type=int, default=4, help="distinct query batches the timed steps rotate over")
     ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--hash-size", type=int, default=0)
     ap.add_argument("--k", type=int, default=10)
@@ -58,26 +75,55 @@ def parse():
     ap.add_argument("--shard", default="buckets", choices=["buckets", "rows"],
                     help="N>1 partition of the corpus: whole buckets per rank (default) or contiguous row ranges")
     ap.add_argument("--pipeline", default="auto", choices=["auto", "on", "off"],
-                    help="on: three-stage pipeline over three HIP streams, encode+plan of batch i+1 and merge(+all-gather) of "
-                         "batch i-1 on high-priority streams beside the scan of batch i.  off: every kernel of a step back "
-                         "to back on one stream (each kernel alone on the chip).  auto: on for N>1 (hides the collective and "
-                         "the per-batch fixed kernels), off for N=1 (worth +2..10 %% there, but the scan kernel's roofline "
-                         "timing is then taken while it shares the chip: --also-other reports the other mode too)")
-    ap.add_argument("--also-other", action="store_true", help="additionally time the K steps in the other mode (reported as `other_mode`)")
+                    help="device-resident region only.  on: three-stage pipeline over three HIP streams; off: every kernel of a "
+                         "step back to back on one stream (each kernel alone on the chip); auto: on for N>1, off for N=1")
     ap.add_argument("--algo", default=None, choices=["query", "bucket", "tiled"], help="force a scan schedule (default: auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--random-init", action="store_true", help="ignore the learned-hash checkpoint")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
-    return ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of each baseline sample")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="launch check only (no GPU needed): start the ranks, rendezvous over gloo, print {n_gpus} and exit")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: run the N ranks as a torchrun child (this process has made no GPU call)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != args.gpus and rank == 0:
-        print(f"[bench] WORLD_SIZE={world} but --gpus={args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus:
+        print(f"[bench] WORLD_SIZE={world} disagrees with --gpus={args.gpus}: refusing to report a {world}-rank run as "
+              f"{args.gpus} GPUs", file=sys.stderr)
+        sys.exit(2)
+    if args.rehearse_launch:
+        if world > 1:
+            dist.init_process_group("gloo")
+        seen = torch.ones((1,), dtype=torch.int64)
+        if world > 1:
+            dist.all_reduce(seen)
+        if rank == 0:
+            print(json.dumps({"rehearse_launch": True, "n_gpus": world, "ranks_seen": int(seen.item())}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if os.environ.get("NLSH_BENCH_SAME_DEVICE"):  # rehearsal of the N>1 path on a one-GPU box (gloo, all ranks on cuda:0)
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -104,14 +150,13 @@ def main():
                         "(synthetic 100-d embeddings on an 8-d latent manifold, synth.glove_manifold, cosine)")}[args.workload]
     N, d, H = args.n or wl["N"], args.dim or wl["d"], args.hash_size or wl["H"]
     args.hash_size_eff = H
-    Q, k, P, metric = args.q, args.k, args.hash_times, wl["metric"]
-    t_setup = time.time()
+    Q, k, P, metric, B = args.q, args.k, args.hash_times, wl["metric"], max(1, args.batches)
     if args.workload == "sift1m":
         corpus_h, mean, std = synth.standardise(synth.sift_manifold(N, d, seed=synth.SEED_DATA))
-        queries_h, _, _ = synth.standardise(synth.sift_manifold(Q, d, seed=synth.SEED_QUERY), mean, std)
+        batches_h = [synth.standardise(synth.sift_manifold(Q, d, seed=synth.SEED_QUERY + 17 * i), mean, std)[0] for i in range(B)]
     else:
         corpus_h = synth.glove_manifold(N, d, seed=synth.SEED_DATA)
-        queries_h = synth.glove_manifold(Q, d, seed=synth.SEED_QUERY)
+        batches_h = [synth.glove_manifold(Q, d, seed=synth.SEED_QUERY + 17 * i) for i in range(B)]
     ckpt = os.path.join(ROOT, "neural-locality-sensitive-hashing_amd", "checkpoints", wl["ckpt"])
     if d == wl["d"] and H == wl["H"] and os.path.exists(ckpt) and not args.random_init:
         arrs = np.load(ckpt)
@@ -132,43 +177,63 @@ def main():
 
     lo, hi = shard_range(N, rank, world)
     shard = torch.from_numpy(corpus_h[lo:hi]).to(dev)
-    queries = torch.from_numpy(queries_h).to(dev)
+    qb = [torch.from_numpy(b).to(dev) for b in batches_h]      # inputs resident in HBM before any timed region
     torch.cuda.synchronize()
     t0 = time.time()
     distance = SIFT.distance if metric == "l2" else Glove.distance
+    sharded = None
     if world > 1:   # build-time exchange (all-gather of keys + all-to-all of rows for --shard buckets) is inside build_s
-        indexer = ShardedIndexer(hashing, shard, distance, id_base=lo, shard=args.shard, compat=H <= 16,
-                                 seg_rows=args.seg_rows, algo=args.algo).local
+        sharded = ShardedIndexer(hashing, shard, distance, id_base=lo, shard=args.shard, compat=H <= 16,
+                                 seg_rows=args.seg_rows, algo=args.algo)
+        indexer = sharded.local
     else:
         indexer = Indexer(hashing, shard, distance, compat=H <= 16, seg_rows=args.seg_rows, algo=args.algo)
     torch.cuda.synchronize()
     build_s = time.time() - t0
     stats = indexer.bucket_stats()
-
     steps, warmup = args.steps, args.warmup
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ------------------------------------------------------------------ region A: the reference's protocol (headline)
+    def query_lists(i):
+        if sharded is not None:
+            return sharded.query(qb[i % B], k=k, hash_times=P, seed=5000 + i)     # same seed on every rank
+        return indexer.query(qb[i % B], k=k, hash_times=P)
+
+    for i in range(max(warmup, 1)):        # at least one: sizes the task table (may retry once); untimed
+        query_lists(-1 - i)
+    fence()
+    call_s = []
+    t0 = time.perf_counter()
+    for i in range(steps):
+        t1 = time.perf_counter()
+        ids_api, nc_api = query_lists(i)
+        call_s.append(time.perf_counter() - t1)
+    fence()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    assert isinstance(ids_api, list) and len(ids_api) == Q and isinstance(nc_api, list)
+
+    # ------------------------------------------------------------------ region B: same path, results left in HBM
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     ev_x = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     for a, b in ev + ev_x:  # instantiate the hipEvent handles
         a.record(); b.record()
-
-    def step(i, check=False, events=None):
-        seed = 1000 + i  # identical on every rank -> identical multi-probe keys
-        dist_, idx_, nc_, k64 = indexer.query_tensors(queries, k=k, hash_times=P, seed=seed, want_keys=world > 1,
-                                                       check=check, events=events)
-        if world > 1:
-            if events is not None:
-                ev_x[i][0].record()
-            dist_, idx_, nc_ = gather_and_merge(k64, nc_, k)
-            if events is not None:
-                ev_x[i][1].record()
-        return dist_, idx_, nc_
-
-    step(-1, check=True)  # sizes the segment table (may retry once); untimed
-    pipe, cur = None, [None]
-
     xchg = TopkExchange(k) if world > 1 else None
+    cur = [None]
 
-    def exchange(k64, nc):   # tail stage of the pipeline on a sharded index: all-gather of per-shard top-k + merge
+    def exchange(k64, nc):   # tail stage on a sharded index: all-gather of per-shard top-k + merge
         i = cur[0]
         if i is not None:
             ev_x[i][0].record()
@@ -178,77 +243,53 @@ def main():
         return out_
 
     use_pipeline = args.pipeline == "on" or (args.pipeline == "auto" and world > 1)
+    pipe = None
     if use_pipeline:
         from nlsh_amd.pipeline import QueryPipeline
-        pipe = QueryPipeline(indexer, queries, k=k, hash_times=P, depth=3, exchange=exchange if world > 1 else None)
+        pipe = QueryPipeline(indexer, qb[0], k=k, hash_times=P, depth=3, exchange=exchange if world > 1 else None)
 
-    def run_step(i, events=None):
-        if pipe is None:
-            return step(i, events=events)
-        cur[0] = i if events is not None else None
-        return pipe.submit(queries, seed=1000 + i, events=events)[:3]
+    def device_step(i, events=None):
+        q = qb[i % B]
+        seed = 1000 + i  # identical on every rank -> identical multi-probe keys
+        if pipe is not None:
+            cur[0] = i if events is not None else None
+            return pipe.submit(q, seed=seed, events=events)[:3]
+        dist_, idx_, nc_, k64 = indexer.query_tensors(q, k=k, hash_times=P, seed=seed, want_keys=world > 1, check=False, events=events)
+        if world > 1:
+            if events is not None:
+                ev_x[i][0].record()
+            dist_, idx_, nc_ = gather_and_merge(k64, nc_, k)
+            if events is not None:
+                ev_x[i][1].record()
+        return dist_, idx_, nc_
 
     for i in range(warmup):
-        run_step(-2 - i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+        device_step(i % B)
+    fence()
     t0 = time.perf_counter()
     for i in range(steps):
-        out = run_step(i, events=ev[i])
+        device_step(i, events=ev[i])
     if pipe is not None:
         pipe.synchronize()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    fence()
+    elapsed_dev = max_over_ranks(time.perf_counter() - t0)
     last_status = pipe.last_slot.status if pipe is not None else indexer.last_status
     n_tasks, overflow = (int(v) for v in last_status.cpu())
     assert overflow == 0 and not (pipe is not None and pipe.overflowed()), "segment table overflow inside the timed region"
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    scan_avg_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
-    other_mode = None
-    if args.also_other and world == 1:
-        from nlsh_amd.pipeline import QueryPipeline
-        alt = QueryPipeline(indexer, queries, k=k, hash_times=P, depth=3) if pipe is None else None
-        for i in range(warmup):
-            alt.submit(queries, seed=i) if alt is not None else step(i)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            alt.submit(queries, seed=1000 + i) if alt is not None else step(i)
-        torch.cuda.synchronize()
-        el2 = time.perf_counter() - t0
-        other_mode = {"mode": "pipeline" if alt is not None else "sequential", "value": Q * steps / el2, "unit": "queries/s",
-                      "ms_per_step": 1e3 * el2 / steps}
-
-    scan_ms = [a.elapsed_time(b) for a, b in ev]
-    scan_avg_ms = float(np.mean(scan_ms))
-    dist_, idx_, nc_ = out
-    local_nc = indexer.query_tensors(queries, k=k, hash_times=P, seed=1000 + steps - 1)[2]
-    sum_c_local = int(local_nc.long().sum().item())
+    # candidates per launch of the timed device steps (untimed recomputation with the same batches and probe seeds)
+    sum_c = []
+    for i in range(steps):
+        sum_c.append(int(indexer.query_tensors(qb[i % B], k=k, hash_times=P, seed=1000 + i)[2].long().sum().item()))
+    sum_c_local = float(np.mean(sum_c))
     algo_bytes = 4.0 * d * sum_c_local
-    achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9
-    # the API-level call (reference return type: Python lists; includes D2H + F7 handling)
-    api_qps = None
-    if world == 1:
-        for _ in range(3):                              # warm-ups (first use of the host-side torch ops), SURVEY.md §8(d)
-            indexer.query(queries, k=k, hash_times=P)
-        times = []
-        for _ in range(10):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            ids_api, nc_api = indexer.query(queries, k=k, hash_times=P)
-            times.append(time.perf_counter() - t0)
-        api_qps = Q / float(np.median(times))           # wall time of the reference-typed call incl. hashing, D2H, list building
+    flops_per_pair = 3.0 * d if metric == "l2" else 2.0 * d      # (q-c), +eps, fma per element | one fma
+    algo_flops = flops_per_pair * sum_c_local
+    t_scan = scan_avg_ms * 1e-3
 
     # encoder (MFMA) utilisation on this rank's corpus rows, and the box's measured HBM copy rate next to the spec peak
-    enc = None
+    enc, copy_gbps = None, None
     if world == 1:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         hashing.hash_device(shard, n=1)
@@ -273,26 +314,52 @@ def main():
         copy_gbps = 2.0 * src.numel() * 4 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
 
-    # HBM traffic per launch: PMC numbers cannot be collected from inside the process; they come from
-    # the committed rocprofv3 --pmc passes of this round (profiles/traffic_r01.json) when the workload matches.
-    traffic, valu_insts = None, None
+    # HBM traffic / VALU instruction counts per launch: PMC numbers cannot be collected from inside the process; they
+    # come from the committed rocprofv3 --pmc passes of this round (taken on the PROFILE box, same workload) when the
+    # workload matches, and are labelled as such.
+    traffic, valu_insts, traffic_src = None, None, None
     try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
+        tr = json.load(open(TRAFFIC_FILE))
         w = tr["workload"]
         if (w["N"], w["d"], w["Q"], w["H"], w["hash_times"]) == (N, d, Q, H, P) and world == 1 and "learned" in hash_desc \
                 and args.workload == "sift1m":
             traffic = tr["traffic_bytes_per_launch"].get(str(indexer.last_algo))
             valu_insts = tr.get("valu_wave_instructions_per_launch", {}).get(str(indexer.last_algo))
+            traffic_src = "profiles/" + os.path.basename(TRAFFIC_FILE) + " (rocprofv3 --pmc on the profile box, same workload; not this run)"
     except (OSError, KeyError, ValueError):
         pass
 
     result = None
     if rank == 0:
-        gt = brute_force_topk(queries, torch.from_numpy(corpus_h).to(dev), k, metric).cpu().numpy()
-        idx_h = idx_.cpu().numpy()
-        recall = float(np.mean(calculate_recall(list(gt), [r[r >= 0].tolist() for r in idx_h])))
-        mean_c = float(nc_.float().mean().item())
+        corpus_d = torch.from_numpy(corpus_h).to(dev)
+        gt = brute_force_topk(qb[0], corpus_d, k, metric).cpu().numpy()
+        del corpus_d
+    ids0, nc0 = query_lists(0)       # every rank takes part in the (collective) protocol call the recall is computed from
+    if rank == 0:
+        recall = float(np.mean(calculate_recall(list(gt), ids0)))
+        mean_c = float(np.mean(nc0))
         value = Q * steps / elapsed
+        algo = indexer.last_algo
+        kernel = {0: "scan_kernel (query-major)", 1: "bscan2_kernel (bucket-major, 8 queries in registers)",
+                  2: "bscan3_kernel (bucket-major, LDS-tiled)"}[algo] + " " + metric
+        if algo == _capi.SCAN_QUERY_MAJOR:
+            roof = {"bound": "hbm", "kernel": kernel, "achieved": algo_bytes / t_scan / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
+        else:
+            roof = {"bound": "valu", "kernel": kernel, "achieved": algo_flops / t_scan / 1e12, "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "note": "bucket-major schedules fetch a row once per query group: fp32 VALU issue binds, not HBM (traffic << algorithmic "
+                            "bytes); achieved = flops_per_pair*d-weighted sum C_q / kernel time; peak = fp32 vector peak (contract's 'mfma' "
+                            "slot does not apply: the distance math is VALU by design, north_star keeps MFMA for the encoder)"}
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof.update({"traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": scan_avg_ms,
+                     "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_GBps": algo_bytes / t_scan / 1e9,
+                     "algorithmic_flops_per_launch": algo_flops, "sum_candidates_per_launch": sum_c_local, "tasks_per_launch": n_tasks})
+        if traffic:
+            roof["hbm_frac_of_measured_traffic"] = traffic / t_scan / 1e9 / HBM_PEAK_GBPS
+        if valu_insts:
+            roof["valu_wave_instructions_per_launch"] = valu_insts
+            roof["valu_issue_frac"] = valu_insts * 2.0 / (1024 * t_scan * 2.4e9)
+        if copy_gbps is not None:
+            roof["hbm_copy_measured_GBps"] = copy_gbps
         result = {
             "metric": "queries/sec + recall@10, SIFT1M 128-d 16-bit hash, 1/2/4/8 GPU" if args.workload == "sift1m" else
                       "queries/sec + recall@10 (GloVe-1.2M 100-d cosine 24-bit: BASELINE.json configs[2], not the headline)",
@@ -300,32 +367,24 @@ def main():
             "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "recall_at_10": recall,
-            "config": {"workload": f"{wl['cfg']}, N={N} d={d} Q={Q} H={H} k={k} hash_times={P}",
+            "value_protocol": "Indexer.query(batch, k, hash_times) -> Python lists, K synchronous calls (nlsh/trainers/base.py:93-96)",
+            "protocol_median_qps": Q / float(np.median(call_s)),
+            "device_resident_qps": Q * steps / elapsed_dev, "device_resident_ms_per_step": 1e3 * elapsed_dev / steps,
+            "config": {"workload": f"{wl['cfg']}, N={N} d={d} Q={Q} H={H} k={k} hash_times={P}, {B} query batches in rotation",
                        "hash": hash_desc,
                        "parallelism": (f"corpus {args.shard} sharded x{world} ({indexer._candidate_vectors_gpu.shape[0]} rows on rank 0), "
                                        f"all-gather of per-shard top-k + merge: {float(np.mean([a.elapsed_time(b) for a, b in ev_x])):.4f} ms/step"
                                        ) if world > 1 else "single GPU",
                        "n_buckets": stats["n_indexes"], "bucket_mean": stats["mean"], "bucket_median": stats["median"],
-                       "bucket_max": stats["max"], "mean_candidates_per_query": mean_c,
-                       "index_build_s": build_s, "api_list_qps": api_qps},
-            "roofline": {"bound": "hbm", "kernel": {0: "scan_kernel (query-major)", 1: "bscan2_kernel (bucket-major, 8 queries in registers)", 2: "bscan3_kernel (bucket-major, LDS-tiled)"}[indexer.last_algo] + " " + metric, "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "note": "achieved = ALGORITHMIC bytes (4*d*sum C_q) / kernel time; the bucket-major schedules fetch each row once per query GROUP, so frac > 1 means HBM traffic (see traffic, bytes/launch from PMC) is far below the algorithmic bytes and the kernel is fp32-VALU-bound",
-                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms,
-                         "sum_candidates_per_launch": sum_c_local, "tasks_per_launch": n_tasks},
+                       "bucket_max": stats["max"], "mean_candidates_per_query": mean_c, "index_build_s": build_s,
+                       "device_step_driver": ("three-stage pipeline over three HIP streams (nlsh_amd/pipeline.py)" if pipe is not None
+                                              else "sequential: every kernel of a step back to back on one stream")},
+            "roofline": roof,
         }
-        result["config"]["step_driver"] = ("three-stage pipeline over three HIP streams (nlsh_amd/pipeline.py)" if pipe is not None
-                                           else "sequential: every kernel of a step back to back on one stream")
-        if other_mode is not None:
-            result["other_mode"] = other_mode
-        if valu_insts:   # the tiled kernel is fp32-VALU-bound: its issue-rate utilisation beside the HBM figure the contract asks for
-            result["roofline"]["valu_wave_instructions_per_launch"] = valu_insts
-            result["roofline"]["valu_issue_frac"] = valu_insts * 2.0 / (1024 * scan_avg_ms * 1e-3 * 2.4e9)
         if enc is not None:
             result["encoder"] = enc
-            result["roofline"]["hbm_copy_measured_GBps"] = copy_gbps
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args, corpus_h, queries_h, Ws, bs, indexer, hashing, queries, steps, metric)
+            result["cpu_baseline"] = cpu_baseline(args, corpus_h, batches_h[0], Ws, bs, indexer, qb[0], metric)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
@@ -342,51 +401,114 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(args, corpus_h, queries_h, Ws, bs, indexer, hashing, queries, steps, metric):
-    """CPU oracle (oracle/: C + OpenMP scan, BLAS forward) on a bounded sample of the same workload:
-    same queries, same multi-probe keys (so identical candidate sets), same k."""
-    from oracle import oracle
+def _cpu_allowance():
+    """(CPUs this process may run on, cgroup cpu.max string): what the lease really gives, next to os.cpu_count()."""
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = os.cpu_count() or 1
+    cg = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            cg = open(path).read().strip()
+            break
+        except OSError:
+            continue
+    cores = affinity
+    if cg:
+        parts = cg.split()
+        try:
+            if len(parts) == 2 and parts[0] != "max":
+                cores = max(1, min(cores, int(float(parts[0]) / float(parts[1]) + 0.5)))
+            elif len(parts) == 1 and int(parts[0]) > 0:
+                cores = max(1, min(cores, int(int(parts[0]) / 100000 + 0.5)))
+        except ValueError:
+            pass
+    return affinity, cg, cores
+
+
+def cpu_baseline(args, corpus_h, queries_h, Ws, bs, indexer, queries, metric):
+    """CPU restatements of the reference's path on a bounded sample of the same workload: same queries, same
+    multi-probe keys (identical candidate sets), same k.  Two restatements are timed and the faster one is `value`:
+    * "port": oracle/ C restatement -- BLAS forward + AVX2/OpenMP scan (8 candidates per lane set, bit-identical to the
+      scalar oracle), at every CPU the lease allows and at 1 thread;
+    * "torch": oracle/torch_restatement.py -- the reference's per-query Python loop over torch-CPU ops
+      (nlsh/indexer.py:56-96: index_select gather -> F.pairwise_distance -> topk), at all cores and at 1 thread."""
+    from oracle import oracle, torch_restatement
     k, P = args.k, args.hash_times
-    keys, nkeys = indexer.hash_device(queries, hash_times=P, seed=1000 + steps - 1)
+    seed = 4242
+    keys, nkeys = indexer.hash_device(queries, hash_times=P, seed=seed)
     kh, nh = keys.cpu().numpy().astype(np.int64), nkeys.cpu().numpy()
     ck = indexer.corpus_keys.cpu().numpy().astype(np.int64)
-    if args.hash_size_eff > 16:  # full-width keys travel as int32 bit patterns
+    mode = "ref_int16" if args.hash_size_eff <= 16 else "full"
+    if mode == "full":  # full-width keys travel as int32 bit patterns
         ck, kh = ck & 0xFFFFFFFF, kh & 0xFFFFFFFF
     perm, uniq, offs = oracle.build_csr(ck)
-    threads = oracle.num_threads()
+    affinity, cgroup, cores = _cpu_allowance()
+    Q = len(queries_h)
 
-    def run(sample):
+    def run_port(sample, simd=True):
         t0 = time.perf_counter()
         z = oracle.mlp_forward_blas(queries_h[:sample], Ws, bs)
         _, p01 = oracle.head_probs(z)
-        oracle.row_keys(p01, P, "ref_int16" if args.hash_size_eff <= 16 else "full", seed=1000 + steps - 1, n_multi_rows=(sample // 4096) * 4096)
+        oracle.row_keys(p01, P, mode, seed=seed, n_multi_rows=(sample // 4096) * 4096)
         t1 = time.perf_counter()
-        oracle.query_batch(corpus_h, perm, uniq, offs, queries_h[:sample], kh[:sample], nh[:sample], k, metric)
-        t2 = time.perf_counter()
-        return t1 - t0, t2 - t1
+        oracle.query_batch(corpus_h, perm, uniq, offs, queries_h[:sample], kh[:sample], nh[:sample], k, metric, simd=simd)
+        return t1 - t0, time.perf_counter() - t1
 
-    Q = len(queries_h)
-    probe = min(Q, 256)
-    th, ts = run(probe)
-    per_q = (th + ts) / probe
-    sample = int(min(Q, max(probe, args.cpu_seconds / max(per_q, 1e-9))))
-    passes, th, ts = 0, 0.0, 0.0
-    while passes == 0 or (th + ts < args.cpu_seconds and passes < 64):     # bounded: ~cpu_seconds of CPU work
-        a, b = run(sample)
-        th, ts, passes = th + a, ts + b, passes + 1
-    out = {"value": sample * passes / (th + ts), "unit": "queries/s", "cores": threads, "kind": "port",
-           "sample": f"first {sample} of {Q} queries x {passes} passes, same keys/candidate sets as the GPU run; "
-                     f"hash {th:.3f}s (numpy BLAS) + scan {ts:.3f}s (C, OpenMP x{threads})",
-           "host_cpu_count": os.cpu_count(), "host_cpu_model": _cpu_model()}
-    # the same restatement on ONE thread (the reference's per-query loop is single-threaded Python over torch ops)
-    oracle.set_num_threads(1)
-    try:
-        one = max(16, min(sample, int(3.0 / max(per_q * threads * 0.5, 1e-9))))
-        t0 = time.perf_counter()
-        oracle.query_batch(corpus_h, perm, uniq, offs, queries_h[:one], kh[:one], nh[:one], k, metric)
-        out["scan_only_1_thread_qps"] = one / (time.perf_counter() - t0)
-    finally:
+    def timed_port(threads, budget_s):
         oracle.set_num_threads(threads)
+        probe = min(Q, 64 * max(1, threads // 8))
+        th, ts = run_port(probe)
+        per_q = (th + ts) / probe
+        sample = int(min(Q, max(probe, budget_s / max(per_q, 1e-9))))
+        passes, th, ts = 0, 0.0, 0.0
+        while passes == 0 or (th + ts < budget_s and passes < 64):
+            a, b = run_port(sample)
+            th, ts, passes = th + a, ts + b, passes + 1
+        return sample * passes / (th + ts), sample, passes, th, ts
+
+    port_all = timed_port(cores, args.cpu_seconds)
+    port_one = timed_port(1, min(args.cpu_seconds, 4.0))
+    oracle.set_num_threads(cores)
+
+    # the torch-CPU restatement: hashing through the torch module forward, scan through the per-query loop
+    index2row = torch_restatement.build_index2row(perm, uniq, offs)
+    corpus_t, queries_t = torch.from_numpy(corpus_h), torch.from_numpy(queries_h)
+    module = indexer._hashing._hasher
+    key_lists = [kh[i, :nh[i]].tolist() for i in range(Q)]
+
+    def timed_torch(threads, budget_s):
+        prev = torch.get_num_threads()
+        torch.set_num_threads(threads)
+        try:
+            cpu_module = copy.deepcopy(module).cpu().eval()
+            sample, total, done = 32, 0.0, 0
+            while total < budget_s and done < Q:
+                n = min(sample, Q - done)
+                t0 = time.perf_counter()
+                with torch.no_grad():
+                    cpu_module(queries_t[done:done + n])                     # hashings.py:66-72 forward (+ sampling on the host)
+                torch_restatement.query(corpus_t, index2row, queries_t[done:done + n], key_lists[done:done + n], k, metric)
+                total += time.perf_counter() - t0
+                done += n
+                sample = min(sample * 2, 1024)
+            return done / total, done
+        finally:
+            torch.set_num_threads(prev)
+
+    torch_all = timed_torch(cores, min(args.cpu_seconds, 8.0))
+    torch_one = timed_torch(1, min(args.cpu_seconds, 4.0))
+    best_port = port_all[0] >= torch_all[0]
+    out = {"value": port_all[0] if best_port else torch_all[0], "unit": "queries/s", "cores": cores,
+           "kind": "port",
+           "restatement": "oracle C (BLAS forward + AVX2/OpenMP scan)" if best_port else "torch-CPU per-query loop (oracle/torch_restatement.py)",
+           "sample": (f"first {port_all[1]} of {Q} queries x {port_all[2]} passes, same keys/candidate sets as the GPU run; "
+                      f"hash {port_all[3]:.3f}s (numpy BLAS) + scan {port_all[4]:.3f}s (C AVX2, OpenMP x{cores})"),
+           "port_qps": {"threads": cores, "value": port_all[0], "one_thread": port_one[0], "thread_scaling": port_all[0] / port_one[0]},
+           "torch_qps": {"threads": cores, "value": torch_all[0], "one_thread": torch_one[0], "queries_timed": torch_all[1],
+                         "note": "reference algorithm restated with torch-CPU ops (python loop per query, as nlsh/indexer.py:56-96)"},
+           "host_cpu_count": os.cpu_count(), "sched_affinity_cpus": affinity, "cgroup_cpu_max": cgroup, "host_cpu_model": _cpu_model()}
     return out
 
 

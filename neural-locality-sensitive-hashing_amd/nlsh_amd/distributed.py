@@ -62,6 +62,10 @@ def gather_and_merge(local_keys: torch.Tensor, local_ncand: torch.Tensor, k: int
     world = dist.get_world_size(group)
     Q = local_keys.shape[0]
     packed = torch.cat([local_keys, local_ncand.to(local_keys.dtype)[:, None]], dim=1).contiguous()
+    if _staged(packed, group):          # gloo rehearsal on device tensors: the collective runs on host copies
+        host = torch.empty((world * Q, k + 1), dtype=packed.dtype)
+        dist.all_gather_into_tensor(host, packed.cpu(), group=group)
+        return merge_fn(host.to(packed.device).view(world, Q, k + 1), k)
     # concatenation form ([world*Q, ...]): accepted by both the nccl (RCCL) and the gloo backend
     packed_all = torch.empty((world * Q, k + 1), dtype=packed.dtype, device=packed.device)
     dist.all_gather_into_tensor(packed_all, packed, group=group)
@@ -134,6 +138,31 @@ def plan_bucket_shards(keys_all: torch.Tensor, world: int):
     return assign_buckets(counts, world)[inverse], corpus_statistics(counts)
 
 
+def _exchange_mode(group) -> str:
+    """"alltoall" | "allgather": how the bucket partition moves rows, decided BEFORE any data collective and agreed
+    by all ranks (a rank that fell back on its own would enter a different collective sequence than its peers and
+    hang them).  NLSH_SHARD_EXCHANGE=allgather forces the gather form; a backend whose `all_to_all_single` with uneven
+    splits fails a zero-byte-safe probe also selects it.  Failures inside the data collectives (out of memory, a lost
+    peer) are NOT caught: they propagate."""
+    want = 0 if os.environ.get("NLSH_SHARD_EXCHANGE", "alltoall") == "allgather" else 1
+    if want:
+        try:                                                        # capability probe: one element to the next rank only
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+            send_counts = [1 if r == (rank + 1) % world else 0 for r in range(world)]
+            recv_counts = [1 if r == (rank - 1) % world else 0 for r in range(world)]
+            out = torch.empty((1,), dtype=torch.int32, device=dev)
+            dist.all_to_all_single(out, torch.full((1,), rank, dtype=torch.int32, device=dev), recv_counts, send_counts, group=group)
+            want = 1 if int(out.item()) == (rank - 1) % world else 0
+        except (RuntimeError, NotImplementedError) as e:
+            warnings.warn(f"all_to_all_single with uneven splits unavailable on this backend ({e}); using the all-gather form")
+            want = 0
+    flag = torch.tensor([want], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device())
+                        if dist.get_backend(group) == "nccl" else torch.device("cpu"))
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)       # every rank takes the same branch
+    return "alltoall" if int(flag.item()) else "allgather"
+
+
 def _staged(t: torch.Tensor, group) -> bool:
     # gloo rehearsals on device tensors go through the host; RCCL ("nccl") works on device memory directly
     return t.device.type == "cuda" and dist.get_backend(group) == "gloo"
@@ -177,19 +206,16 @@ def exchange_rows_by_bucket(local_rows: torch.Tensor, local_keys: torch.Tensor, 
     owner_all, stats = plan_bucket_shards(keys_all, world)
     n_local = local_rows.shape[0]
     ids_local = torch.arange(n_local, device=local_rows.device, dtype=torch.int32) + int(id_base)
-    if os.environ.get("NLSH_SHARD_EXCHANGE", "alltoall") == "alltoall":
-        try:
-            dest = owner_all[start:start + n_local]
-            order = torch.argsort(dest, stable=True)                   # keeps ascending row order per destination
-            send_counts = torch.bincount(dest, minlength=world)
-            counts_all = _all_gather_rows(send_counts.view(1, world), group)  # [G, G]: row r = what rank r sends
-            recv_counts = counts_all[:, rank].cpu().tolist()
-            send_counts = send_counts.cpu().tolist()
-            rows = _all_to_all_rows(local_rows[order], send_counts, recv_counts, group)
-            ids = _all_to_all_rows(ids_local[order], send_counts, recv_counts, group)
-            return rows, ids, stats
-        except (RuntimeError, NotImplementedError) as e:     # a backend without all_to_all_single: same result, more traffic
-            warnings.warn(f"all_to_all_single unavailable ({e}); falling back to an all-gather of the rows")
+    if _exchange_mode(group) == "alltoall":
+        dest = owner_all[start:start + n_local]
+        order = torch.argsort(dest, stable=True)                   # keeps ascending row order per destination
+        send_counts = torch.bincount(dest, minlength=world)
+        counts_all = _all_gather_rows(send_counts.view(1, world), group)  # [G, G]: row r = what rank r sends
+        recv_counts = counts_all[:, rank].cpu().tolist()
+        send_counts = send_counts.cpu().tolist()
+        rows = _all_to_all_rows(local_rows[order], send_counts, recv_counts, group)
+        ids = _all_to_all_rows(ids_local[order], send_counts, recv_counts, group)
+        return rows, ids, stats
     # fallback (NLSH_SHARD_EXCHANGE=allgather): every rank gathers all rows and keeps the ones it owns -- G times the
     # traffic of the all-to-all, the same rows in the same (ascending global id) order
     mine = torch.nonzero(owner_all == rank).view(-1)
@@ -235,3 +261,43 @@ class ShardedIndexer:
         if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
             return merge_topk_device(torch.cat([keys64, ncand.long()[:, None]], dim=1)[None], k)
         return gather_and_merge(keys64, ncand, k, self.group)
+
+    def query(self, query_vectors, k=10, hash_times=10, seed=None):
+        """`Indexer.query` (nlsh/indexer.py:56-96) over the sharded corpus: the reference's `(List[List[int]],
+        List[int])` on EVERY rank, identical to the single-GPU answer.  hash -> local scan -> all-gather + merge -> one
+        device->host copy.  The multi-probe seed comes from the hasher's call counter (identical on all ranks as long
+        as they make the same calls) unless given."""
+        import numpy as np
+        local = self.local
+        if seed is None:
+            seed = local._hashing.next_seed()
+        keys, nkeys = local.hash_device(query_vectors, hash_times=hash_times, seed=seed)
+        _, _, ncand, keys64 = local.scan_tensors(query_vectors, keys, nkeys, k=k, want_keys=True)
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if world == 1:
+            _, idx, nc = merge_topk_device(torch.cat([keys64, ncand.long()[:, None]], dim=1)[None], k)
+        else:
+            _, idx, nc = gather_and_merge(keys64, ncand, k, self.group)
+        idx_h, nc_h = idx.cpu().numpy(), nc.cpu().numpy()
+        short = np.nonzero(nc_h < k)[0]
+        key_sets = {}
+        if local.compat and short.size:
+            from .hashings import keys_to_sets
+            sel = torch.as_tensor(short, device=keys.device)
+            key_sets = dict(zip(short.tolist(), keys_to_sets(keys[sel], nkeys[sel], local._hashing.key_mode)))
+        results, counts = local._plain_lists(idx_h, nc_h)                        # short lists are replaced below
+        if short.size:
+            if local.compat:
+                # F7 (indexer.py:91-93): rows of the LAST key of the set; the bucket lives on one rank (bucket partition)
+                # or is split over all (row partition), so the ranks pool their parts (rare path: C_q < k)
+                mine = [local._rows_of_key(list(key_sets[qi])[-1]) if key_sets[qi] else [] for qi in short.tolist()]
+                if world > 1:
+                    pooled = [None] * world
+                    dist.all_gather_object(pooled, mine, group=self.group)
+                    mine = [sorted(sum((p[i] for p in pooled), [])) for i in range(len(mine))]
+                for qi, rows in zip(short.tolist(), mine):
+                    results[qi] = rows
+            else:
+                for qi in short.tolist():
+                    results[qi] = [int(v) for v in idx_h[qi] if v >= 0]
+        return results, counts

@@ -11,6 +11,7 @@ computation with device-resident results (what bench.py times).  compat=True (de
 reference quirks: int16 key wrap (F2), single-probe trailing partial batch (F6), `<k` fallback =
 last key's bucket rows (F7).  No CPU fallback exists anywhere in this module.
 """
+import gc
 from typing import Dict, List, Optional, Sequence, Set, Tuple
 
 import numpy as np
@@ -105,6 +106,7 @@ class Indexer:
         self._index2row = None
         self._perm_host = None
         self._e_sb = None
+        self._pin = None            # pinned host staging of query()'s single device->host copy
         self._ws = {}               # scan workspace per stream (concurrent query batches on different HIP streams)
         self._max_tasks = {}
         self._build_index()
@@ -239,16 +241,20 @@ class Indexer:
         P = keys.shape[1]
         seg = self.seg_rows or 512
         out_dist = torch.empty((Q, k), dtype=torch.float32, device=dev)
-        out_idx = torch.empty((Q, k), dtype=torch.int32, device=dev)
+        # ids, candidate counts and the two status words share ONE int32 buffer: `query()` brings all three to the host
+        # with a single copy (and a single synchronisation) instead of four
+        pack = torch.empty((Q * k + Q + 2,), dtype=torch.int32, device=dev)
+        out_idx, ncand, status = pack[:Q * k].view(Q, k), pack[Q * k:Q * k + Q], pack[Q * k + Q:]
         out_keys = torch.empty((Q, k), dtype=torch.int64, device=dev) if want_keys else None
-        ncand = torch.empty((Q,), dtype=torch.int32, device=dev)
-        status = torch.empty((2,), dtype=torch.int32, device=dev)
-        metric = _capi.METRIC_L2_EPS if self.metric == "l2" else _capi.METRIC_COSINE
         algo = self.choose_algo(Q, P)
-        if algo not in self._max_tasks:
-            self._max_tasks[algo] = self._estimate_tasks(Q, P, seg, algo)
+        # the task table is sized per (schedule, batch shape): a larger batch after a smaller one re-estimates instead of
+        # reusing a table that `check=False` callers would silently overflow
+        tkey = (algo, Q, P)
+        if tkey not in self._max_tasks:
+            grown = [v for (a_, q_, p_), v in self._max_tasks.items() if a_ == algo and q_ >= Q and p_ >= P]
+            self._max_tasks[tkey] = min(grown) if grown else self._estimate_tasks(Q, P, seg, algo)
         while True:
-            max_tasks = self._max_tasks[algo]
+            max_tasks = self._max_tasks[tkey]
             ws_bytes = L.nlsh_scan_workspace(Q, P, k, max_tasks, self.n_buckets, d)
             stream = _stream(dev)
             ws = self._ws.get(stream)
@@ -261,9 +267,10 @@ class Indexer:
             needed, overflow = status.cpu().tolist()
             if not overflow:
                 break
-            self._max_tasks[algo] = int(needed * 1.25) + 1024      # segment table too small: grow and repeat
+            self._max_tasks[tkey] = int(needed * 1.25) + 1024      # segment table too small: grow and repeat
         self.last_status = status
         self.last_algo = algo
+        self._last_pack, self._last_tkey = pack, tkey
         return out_dist, out_idx, ncand, out_keys
 
     def _scan_args(self, Q, d, keys, nkeys, k, algo, max_tasks, out_dist, out_idx, out_keys, ncand, status, ws):
@@ -327,10 +334,39 @@ class Indexer:
             self._perm_host = self.gid.cpu().numpy().astype(np.int64)
         return self._perm_host[lo:hi].tolist()
 
-    def _to_lists(self, key_sets: Sequence[Sequence[int]], idx, ncand, k):
-        idx_h = idx.cpu().numpy()
-        nc_h = ncand.cpu().numpy()
-        results = idx_h.tolist()                      # one C-level conversion for the whole batch
+    def _host_results(self, q, keys, nkeys, k):
+        """Scan + ONE device->host copy of (ids, candidate counts, status) into a pinned buffer + one stream
+        synchronisation: the only sync of a `query()` call.  Repeats the scan if the task table overflowed."""
+        while True:
+            _, idx, ncand, _ = self.scan_tensors(q, keys, nkeys, k=k, check=False)
+            pack, tkey = self._last_pack, self._last_tkey
+            n = pack.numel()
+            pin = self._pin
+            if pin is None or pin.numel() < n:
+                pin = self._pin = torch.empty((max(n, 1 << 16),), dtype=torch.int32, pin_memory=True)
+            pin[:n].copy_(pack, non_blocking=True)
+            torch.cuda.current_stream(q.device).synchronize()
+            host = pin[:n].numpy()
+            Q = q.shape[0]
+            needed, overflow = int(host[n - 2]), int(host[n - 1])
+            if not overflow or Q == 0:
+                return host[:Q * k].reshape(Q, k), host[Q * k:Q * k + Q]
+            self._max_tasks[tkey] = int(needed * 1.25) + 1024
+
+    @staticmethod
+    def _plain_lists(idx_h, nc_h):
+        """Host arrays -> (list of id rows, list of counts): one C-level conversion each for the whole batch."""
+        was_enabled = gc.isenabled()
+        gc.disable()        # 10^4 fresh lists would trigger a dozen collections over the whole heap: a third of the conversion
+        try:
+            return idx_h.tolist(), nc_h.tolist()
+        finally:
+            if was_enabled:
+                gc.enable()
+
+    def _to_lists(self, key_sets, idx_h, nc_h, k):
+        """Host arrays -> the reference's (List[List[int]], List[int]) (indexer.py:88-95)."""
+        results, counts = self._plain_lists(idx_h, nc_h)
         for qi in np.nonzero(nc_h < k)[0].tolist():   # only the short queries need the reference's special case
             if self.compat:
                 # indexer.py:89-93 (F7): topk raises -> rows of the LAST key of the set iteration
@@ -338,20 +374,34 @@ class Indexer:
                 results[qi] = self._rows_of_key(order[-1]) if order else []
             else:
                 results[qi] = [int(v) for v in idx_h[qi] if v >= 0]
-        return results, nc_h.tolist()
+        return results, counts
 
     def query(self, query_vectors, k=10, hash_times=10) -> Tuple[List[List[int]], List[int]]:
         if self.metric not in ("l2", "cosine"):
             return self._query_generic(query_vectors, k, hash_times)
-        keys, nkeys = self.hash_device(query_vectors, hash_times=hash_times)
-        _, idx, ncand, _ = self.scan_tensors(query_vectors, keys, nkeys, k=k)
+        q = self._as_queries(query_vectors)
+        keys, nkeys = self.hash_device(q, hash_times=hash_times)
+        if keys.shape[1] > _capi.MAX_PROBES:
+            _, idx, ncand, _ = self.scan_tensors(q, keys, nkeys, k=k)
+            idx_h, nc_h = idx.cpu().numpy(), ncand.cpu().numpy()
+        else:
+            idx_h, nc_h = self._host_results(q, keys, nkeys, k)
         key_sets = {}
         if self.compat:  # F7 needs the key SET (Python iteration order) of the queries with < k candidates only
-            short = torch.nonzero(ncand < k).view(-1)
-            if short.numel():
-                sets = keys_to_sets(keys[short], nkeys[short], self._hashing.key_mode)
-                key_sets = dict(zip(short.cpu().tolist(), sets))
-        return self._to_lists(key_sets, idx, ncand, k)
+            short = np.nonzero(nc_h < k)[0]
+            if short.size:
+                sel = torch.as_tensor(short, device=keys.device)
+                sets = keys_to_sets(keys[sel], nkeys[sel], self._hashing.key_mode)
+                key_sets = dict(zip(short.tolist(), sets))
+        return self._to_lists(key_sets, idx_h, nc_h, k)
+
+    def _as_queries(self, query_vectors):
+        q = query_vectors
+        if q.device.type != "cuda":
+            raise _capi.NlshHipError(_capi.E_INVALID, "queries must be device-resident; there is no CPU path")
+        if q.dtype != torch.float32 or q.stride(1) != 1:
+            q = q.float().contiguous()
+        return q
 
     def query_with_keys(self, query_vectors, key_lists: Sequence[Sequence[int]], k=10):
         """Scan stage on caller-supplied key lists (each in the iteration order the caller saw):
@@ -368,7 +418,7 @@ class Indexer:
         keys = torch.as_tensor(tab).to(dev)
         nkeys = torch.as_tensor(cnt).to(dev)
         dist, idx, ncand, _ = self.scan_tensors(query_vectors, keys, nkeys, k=k)
-        res, nc = self._to_lists(key_lists, idx, ncand, k)
+        res, nc = self._to_lists(key_lists, idx.cpu().numpy(), ncand.cpu().numpy(), k)
         return res, nc, dist, idx
 
     def _global_ids(self, local_rows):
@@ -381,17 +431,21 @@ class Indexer:
         results, n_candidates = [], []
         corpus = self._candidate_vectors_gpu
         for qi, ks in enumerate(key_sets):
-            chunks = []
+            chunks, last = [], None
             for key in list(ks):
                 kk = int(key) - (1 << 32) if int(key) >= (1 << 31) else int(key)
                 i = int(np.searchsorted(self._uniq_host, kk))
+                last = None                                          # indexer.py:68,92: the last key's rows, [] if it has no bucket
                 if i < len(self._uniq_host) and int(self._uniq_host[i]) == kk:
-                    chunks.append(self.perm[int(self._offs_host[i]):int(self._offs_host[i + 1])].long())
+                    last = self.perm[int(self._offs_host[i]):int(self._offs_host[i + 1])].long()
+                    chunks.append(last)
             rows = torch.cat(chunks) if chunks else torch.zeros((0,), dtype=torch.int64, device=corpus.device)
             n_candidates.append(int(rows.numel()))
             if rows.numel() >= k:
                 dist = self._distance_func(query_vectors[qi], corpus[rows])
                 results.append(self._global_ids(rows[dist.topk(k, largest=False)[1]]).tolist())
+            elif self.compat:
+                results.append([] if last is None else self._global_ids(last).tolist())
             else:
-                results.append(self._global_ids(chunks[-1] if chunks and self.compat else rows).tolist())
+                results.append(self._global_ids(rows).tolist())
         return results, n_candidates

@@ -16,6 +16,13 @@ per-batch buffers (key table, task-table workspace, outputs); a slot is reused o
 finished (event).  Results are bit-identical to `Indexer.query_tensors`: the kernels and their arguments are the
 same, only the stream they run on differs.  No reference counterpart (the reference answers one query at a time,
 nlsh/indexer.py:62-95).
+
+Buffer lifetimes: a submitted batch is read by all three streams after `submit` returns.  `submit` therefore marks the
+batch tensor as in use on the front, mid and tail streams (`record_stream`), so the caching allocator will not hand its
+memory to a later allocation until those streams have passed the batch -- the caller may drop the tensor at once, but
+must not OVERWRITE it in place before `synchronize()` (or the batch's results) say the batch is done.  The packed
+encoder weights are owned by the pipeline (a reference is held) and re-read from the hasher whenever its parameters
+changed since the last submit (a training step, `load_state`, a device move), so slots never keep a dangling pointer.
 """
 from typing import Callable, Optional
 
@@ -48,7 +55,7 @@ class QueryPipeline:
         indexer.query_tensors(q, k=k, hash_times=hash_times, seed=0, check=True)     # sizes indexer._max_tasks
         torch.cuda.synchronize(dev)
         self.algo = indexer.last_algo
-        self.max_tasks = indexer._max_tasks[self.algo]
+        self.max_tasks = indexer._max_tasks[(self.algo, self.Q, self.P)]
         ws_bytes = _capi.lib().nlsh_scan_workspace(self.Q, self.P, k, self.max_tasks, indexer.n_buckets, self.d)
         # the front and tail stages are small workgroups that must slip in beside the scan: their queues get the
         # higher priority
@@ -73,25 +80,42 @@ class QueryPipeline:
             # is what bounded the pipeline on small shards)
             s.scan_pre, s.scan_post = indexer._scan_args(self.Q, self.d, s.keys, s.nkeys, k, self.algo, self.max_tasks, s.out_dist,
                                                          s.out_idx, s.out_keys, s.ncand, s.status, s.ws)
-            s.enc_pre, s.enc_post = indexer._hashing.encode_args(self.P, s.keys, s.nkeys)
             self.slots.append(s)
+        self._bind_weights()
         self._lib = _capi.lib()
         self._n_multi = indexer._n_multi_rows(self.Q)
         self.n_submitted = 0
         self.last_slot = None
 
+    def _bind_weights(self):
+        """(Re)build the fixed part of every slot's encode call from the hasher's CURRENT weights and keep the packed
+        blob alive for as long as the slots point at it."""
+        h = self.indexer._hashing
+        self._packed = h.packed_weights()
+        self._packed.record_stream(self.front)      # read by encode_hash on the front stream, allocated on the caller's
+        self._weights_sig = h._weights_signature()
+        for s in self.slots:
+            s.enc_pre, s.enc_post = h.encode_args(self.P, s.keys, s.nkeys)
+            assert s.enc_pre[2] == self._packed.data_ptr()
+
     def submit(self, queries, seed=None, events=None):
         """Enqueue one batch; returns (dist, idx, ncand, keys64 | None) -- device tensors owned by the batch's slot
         (or fresh ones from `exchange`), valid once the tail stream has passed the batch (`synchronize()`), and
         overwritten `depth` submits later.  `events`: (begin, end) pair recorded around the scan kernel.
-        The hasher's weights are the ones present when the pipeline was built."""
+        The hasher's weights are the ones present at THIS call."""
         if queries.shape != (self.Q, self.d) or queries.dtype != torch.float32 or queries.stride(1) != 1:
             raise ValueError("batch shape/dtype differs from the pipeline's sample batch")
         ix, L = self.indexer, self._lib
         s = self.slots[self.n_submitted % len(self.slots)]
         self.n_submitted += 1
         front, mid, tail = self.front, self.mid, self.tail
+        if ix._hashing._weights_signature() != self._weights_sig:
+            if self.n_submitted > 1:
+                torch.cuda.current_stream(queries.device).wait_stream(front)   # batches in flight still read the old blob
+            self._bind_weights()
         front.wait_stream(torch.cuda.current_stream(queries.device))        # the batch may still be in flight there
+        for st in (front, mid, tail):                                       # all three stages read the batch tensor
+            queries.record_stream(st)
         front.wait_event(s.done)                                            # the slot's previous batch has left the tail
         qp, qs = queries.data_ptr(), queries.stride(0)
         if seed is None:

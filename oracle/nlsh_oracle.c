@@ -271,6 +271,134 @@ void oracle_query_batch(const float *corpus, int d, const int32_t *perm, const i
     }
 }
 
+/* ------------------------------------------------------------------ the same scan, 8 candidates per AVX2 lane set
+ * bench.py's cpu_baseline times THIS form (the scalar loop above is a 4-cycle-latency dependent fmaf chain per
+ * candidate, i.e. latency- not bandwidth-bound, which is not what a tuned CPU implementation would run).  Lane l of a
+ * vector follows candidate l's OWN k-ascending chain ((q_j - c_j) + eps, fmaf), so every distance has the same bits as
+ * oracle_l2 / oracle_cosine and the result is identical to oracle_query_batch (tests/test_oracle_golden.py checks
+ * that); rows of 8 candidates are brought in as 8x8 blocks and transposed in registers. */
+#include <immintrin.h>
+
+static inline void transpose8(__m256 r[8]) {
+    __m256 t0 = _mm256_unpacklo_ps(r[0], r[1]), t1 = _mm256_unpackhi_ps(r[0], r[1]);
+    __m256 t2 = _mm256_unpacklo_ps(r[2], r[3]), t3 = _mm256_unpackhi_ps(r[2], r[3]);
+    __m256 t4 = _mm256_unpacklo_ps(r[4], r[5]), t5 = _mm256_unpackhi_ps(r[4], r[5]);
+    __m256 t6 = _mm256_unpacklo_ps(r[6], r[7]), t7 = _mm256_unpackhi_ps(r[6], r[7]);
+    __m256 u0 = _mm256_shuffle_ps(t0, t2, 0x44), u1 = _mm256_shuffle_ps(t0, t2, 0xEE);
+    __m256 u2 = _mm256_shuffle_ps(t1, t3, 0x44), u3 = _mm256_shuffle_ps(t1, t3, 0xEE);
+    __m256 u4 = _mm256_shuffle_ps(t4, t6, 0x44), u5 = _mm256_shuffle_ps(t4, t6, 0xEE);
+    __m256 u6 = _mm256_shuffle_ps(t5, t7, 0x44), u7 = _mm256_shuffle_ps(t5, t7, 0xEE);
+    r[0] = _mm256_permute2f128_ps(u0, u4, 0x20); r[1] = _mm256_permute2f128_ps(u1, u5, 0x20);
+    r[2] = _mm256_permute2f128_ps(u2, u6, 0x20); r[3] = _mm256_permute2f128_ps(u3, u7, 0x20);
+    r[4] = _mm256_permute2f128_ps(u0, u4, 0x31); r[5] = _mm256_permute2f128_ps(u1, u5, 0x31);
+    r[6] = _mm256_permute2f128_ps(u2, u6, 0x31); r[7] = _mm256_permute2f128_ps(u3, u7, 0x31);
+}
+
+/* distances of 8 candidates (row pointers c[0..7]) to one query; qn = q / max(|q|, 1e-8) for cosine (else unused) */
+static void dist8(const float *q, const float *qn, const float *const c[8], int d, int metric, float out[8]) {
+    const __m256 eps = _mm256_set1_ps(1e-6f);
+    __m256 acc = _mm256_setzero_ps(), cc = _mm256_setzero_ps(), cn = _mm256_setzero_ps();
+    const int d8 = d & ~7;
+    if (metric != 0) {   /* cosine: the candidates' norms first (their own k-ascending chains) */
+        for (int j = 0; j < d8; j += 8) {
+            __m256 r[8];
+            for (int l = 0; l < 8; ++l) r[l] = _mm256_loadu_ps(c[l] + j);
+            transpose8(r);
+            for (int t = 0; t < 8; ++t) cc = _mm256_fmadd_ps(r[t], r[t], cc);
+        }
+        for (int j = d8; j < d; ++j) {
+            __m256 col = _mm256_set_ps(c[7][j], c[6][j], c[5][j], c[4][j], c[3][j], c[2][j], c[1][j], c[0][j]);
+            cc = _mm256_fmadd_ps(col, col, cc);
+        }
+        cn = _mm256_max_ps(_mm256_sqrt_ps(cc), _mm256_set1_ps(1e-8f));
+    }
+    for (int j = 0; j < d8; j += 8) {
+        __m256 r[8];
+        for (int l = 0; l < 8; ++l) r[l] = _mm256_loadu_ps(c[l] + j);
+        transpose8(r);
+        for (int t = 0; t < 8; ++t) {
+            if (metric == 0) {
+                __m256 v = _mm256_add_ps(_mm256_sub_ps(_mm256_set1_ps(q[j + t]), r[t]), eps);
+                acc = _mm256_fmadd_ps(v, v, acc);
+            } else {
+                acc = _mm256_fmadd_ps(_mm256_set1_ps(qn[j + t]), _mm256_div_ps(r[t], cn), acc);
+            }
+        }
+    }
+    for (int j = d8; j < d; ++j) {
+        __m256 col = _mm256_set_ps(c[7][j], c[6][j], c[5][j], c[4][j], c[3][j], c[2][j], c[1][j], c[0][j]);
+        if (metric == 0) {
+            __m256 v = _mm256_add_ps(_mm256_sub_ps(_mm256_set1_ps(q[j]), col), eps);
+            acc = _mm256_fmadd_ps(v, v, acc);
+        } else {
+            acc = _mm256_fmadd_ps(_mm256_set1_ps(qn[j]), _mm256_div_ps(col, cn), acc);
+        }
+    }
+    if (metric == 0) acc = _mm256_sqrt_ps(acc);
+    else acc = _mm256_sub_ps(_mm256_set1_ps(1.0f), acc);
+    _mm256_storeu_ps(out, acc);
+}
+
+static inline void topk_push(float *bd, int32_t *bi, int *have, int k, float dist, int32_t row) {
+    if (*have == k && !(dist < bd[k - 1] || (dist == bd[k - 1] && row < bi[k - 1]))) return;
+    int pos = *have < k ? *have : k - 1;
+    while (pos > 0 && (dist < bd[pos - 1] || (dist == bd[pos - 1] && row < bi[pos - 1]))) {
+        bd[pos] = bd[pos - 1]; bi[pos] = bi[pos - 1]; --pos;
+    }
+    bd[pos] = dist; bi[pos] = row;
+    if (*have < k) ++*have;
+}
+
+void oracle_query_batch_simd(const float *corpus, int d, const int32_t *perm, const int64_t *uniq_keys,
+                             const int64_t *offsets, int64_t nb, const float *queries, int64_t Q,
+                             const int64_t *qkeys, const int32_t *nkeys, int P, int k, int metric,
+                             float *out_dist, int32_t *out_idx, int64_t *out_ncand) {
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+    {
+        float *qn = (float *)malloc(sizeof(float) * (size_t)(d > 0 ? d : 1));
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4)
+#endif
+        for (int64_t q = 0; q < Q; ++q) {
+            const float *qv = queries + (size_t)q * d;
+            float *bd = out_dist + (size_t)q * k;
+            int32_t *bi = out_idx + (size_t)q * k;
+            int have = 0;
+            int64_t nc = 0;
+            for (int t = 0; t < k; ++t) { bd[t] = INFINITY; bi[t] = -1; }
+            if (metric != 0) {
+                float qq = 0.0f;
+                for (int j = 0; j < d; ++j) qq = fmaf(qv[j], qv[j], qq);
+                const float nrm = fmaxf(sqrtf(qq), 1e-8f);
+                for (int j = 0; j < d; ++j) qn[j] = qv[j] / nrm;
+            }
+            for (int p = 0; p < nkeys[q]; ++p) {
+                int64_t bkt = find_bucket(uniq_keys, nb, qkeys[(size_t)q * P + p]);
+                if (bkt < 0) continue;
+                int64_t i = offsets[bkt];
+                const int64_t end = offsets[bkt + 1];
+                nc += end - i;
+                for (; i + 8 <= end; i += 8) {
+                    const float *c[8];
+                    float dist[8];
+                    for (int l = 0; l < 8; ++l) c[l] = corpus + (size_t)perm[i + l] * d;
+                    dist8(qv, qn, c, d, metric, dist);
+                    for (int l = 0; l < 8; ++l) topk_push(bd, bi, &have, k, dist[l], perm[i + l]);
+                }
+                for (; i < end; ++i) {
+                    const int32_t row = perm[i];
+                    const float *c = corpus + (size_t)row * d;
+                    topk_push(bd, bi, &have, k, metric == 0 ? oracle_l2(qv, c, d) : oracle_cosine(qv, c, d), row);
+                }
+            }
+            out_ncand[q] = nc;
+        }
+        free(qn);
+    }
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     extern int omp_get_max_threads(void);

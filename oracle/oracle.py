@@ -181,8 +181,9 @@ def distances(q, corpus, rows, metric="l2", f64=False):
     return (o32, o64) if f64 else o32
 
 
-def query_batch(corpus, perm, uniq_keys, offsets, queries, qkeys, nkeys, k, metric="l2"):
+def query_batch(corpus, perm, uniq_keys, offsets, queries, qkeys, nkeys, k, metric="l2", simd=False):
     """Gather + distance + top-k for every query (indexer.py:62-95) on a CSR index.
+    simd=True: the AVX2 form (8 candidates per lane set, same bits; what bench.py's cpu_baseline times).
 
     Returns (dist fp32 [Q,k] +inf padded, idx int32 [Q,k] -1 padded, ncand int64 [Q]);
     order = (distance, row id) ascending.
@@ -201,7 +202,8 @@ def query_batch(corpus, perm, uniq_keys, offsets, queries, qkeys, nkeys, k, metr
     od = np.empty((Q, k), dtype=np.float32)
     oi = np.empty((Q, k), dtype=np.int32)
     nc = np.empty(Q, dtype=np.int64)
-    lib().oracle_query_batch(_p(corpus, c_f32p), corpus.shape[1], _p(perm, c_i32p), _p(uniq_keys, c_i64p),
+    fn = lib().oracle_query_batch_simd if simd else lib().oracle_query_batch
+    fn(_p(corpus, c_f32p), corpus.shape[1], _p(perm, c_i32p), _p(uniq_keys, c_i64p),
                              _p(offsets, c_i64p), ctypes.c_int64(len(uniq_keys)), _p(queries, c_f32p),
                              ctypes.c_int64(Q), _p(qkeys, c_i64p), _p(nkeys, c_i32p), P, k,
                              0 if metric == "l2" else 1, _p(od, c_f32p), _p(oi, c_i32p), _p(nc, c_i64p))

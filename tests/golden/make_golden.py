@@ -27,6 +27,7 @@ import pyximport  # noqa: E402
 
 pyximport.install(setup_args={"include_dirs": np.get_include()}, build_dir="/tmp/nlsh_oracle_pyxbld")
 for _name, _attrs in (("siren", {"SIREN": object}), ("h5py", {"File": None}),
+                      ("hnswlib", {"Index": object}),      # nlsh/trainers/__init__.py:10 pulls it; never called here
                       ("dotenv", {"load_dotenv": lambda *a, **k: None})):
     if _name not in sys.modules:
         _m = types.ModuleType(_name)
@@ -270,8 +271,28 @@ def g7():
                         ground_truth=gt.astype(np.int32))
 
 
+def g8():
+    """Training-side formulas the minimal trainer restates: triplet loss (nlsh/trainers/triplet.py:16-26) on the
+    Bernoulli-code L2 distance (nlsh/learning/distances.py:245-254), values + gradients on seeded probabilities."""
+    from nlsh.trainers.triplet import triplet_loss
+    from nlsh.learning.distances import MVBernoulliL2
+    rng = np.random.default_rng(808)
+    arrays = {}
+    for name, (n, H, margin) in {"a": (64, 16, 0.1), "b": (33, 24, 1.0), "c": (8, 8, 0.0)}.items():
+        pa, pp, pn = (rng.uniform(0.01, 0.99, size=(n, H)).astype(np.float32) for _ in range(3))
+        pp[:3] = pa[:3]                                    # zero positive distance rows
+        ta, tp, tn = (torch.from_numpy(x).requires_grad_(True) for x in (pa, pp, pn))
+        dist_fn = MVBernoulliL2().rowwise
+        loss = triplet_loss(ta, tp, tn, dist_fn, margin=margin)
+        loss.backward()
+        arrays.update({f"{name}_anchor": pa, f"{name}_pos": pp, f"{name}_neg": pn, f"{name}_margin": np.float32(margin),
+                       f"{name}_d_pos": dist_fn(ta, tp).detach().numpy(), f"{name}_loss": loss.detach().numpy(),
+                       f"{name}_grad_anchor": ta.grad.numpy(), f"{name}_grad_neg": tn.grad.numpy()})
+    np.savez_compressed(os.path.join(HERE, "g8_triplet.npz"), **arrays)
+
+
 if __name__ == "__main__":
-    g1(); g2(); g3(); g4(); g5(); g7()
+    g1(); g2(); g3(); g4(); g5(); g7(); g8()
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith((".json", ".npz")):
             print(f"{fn}: {os.path.getsize(os.path.join(HERE, fn))} bytes")

@@ -54,3 +54,51 @@ def check_topk_against_candidates(idx_row, dist_row, cand_rows, cand_d64, k, rto
         rest = np.array([v for r, v in d_of.items() if r not in set(ids)])
         if len(rest):
             assert rest.min() >= kth - rtol * max(1.0, abs(kth)), "a closer candidate was missed"
+
+
+def check_scan_properties(ix, qg, cg, keys, nkeys, dist, idx, nc, k, metric, rtol=2e-5):
+    """Size-independent properties of one scan result on a full-size index (the oracle cannot brute-force these
+    sizes): candidate counts vs an independent torch recomputation, membership of every returned id in one of the
+    query's probed buckets, ascending order, no duplicates, distances vs stock torch ops (nlsh/data.py:99-109,191-201)."""
+    d = cg.shape[1]
+    pos = torch.searchsorted(ix.uniq_keys, keys.clamp(min=int(ix.uniq_keys.min()), max=int(ix.uniq_keys.max())))
+    pos = pos.clamp(max=ix.n_buckets - 1)
+    hit = ix.uniq_keys[pos] == keys
+    sizes = (ix.offsets[1:] - ix.offsets[:-1])[pos] * hit
+    valid = torch.arange(keys.shape[1], device=keys.device)[None, :] < nkeys[:, None]
+    assert torch.equal((sizes * valid).sum(1).int(), nc), "n_candidates != sum of probed bucket sizes"
+    ok = idx >= 0
+    assert torch.equal(ok.sum(1).int(), nc.clamp(max=k)), "a query returned fewer ids than min(k, C_q)"
+    ck = ix.corpus_keys[idx.clamp(min=0).long()]
+    member = ((ck[:, :, None] == keys[:, None, :]) & valid[:, None, :]).any(-1)
+    assert bool((member | ~ok).all()), "a returned id is not in a probed bucket"
+    assert bool((dist[:, 1:] >= dist[:, :-1]).all()), "distances not ascending"
+    srt = torch.sort(idx, dim=1).values
+    assert bool(((srt[:, 1:] != srt[:, :-1]) | (srt[:, 1:] < 0)).all()), "duplicate ids"
+    qq = qg[:, None, :].expand(-1, k, -1).reshape(-1, d)
+    cc = cg[idx.clamp(min=0).long().reshape(-1)]
+    if metric == "l2":
+        ref = torch.nn.functional.pairwise_distance(qq, cc).reshape(-1, k)
+    else:
+        ref = (1 - torch.nn.functional.cosine_similarity(qq, cc, dim=-1)).reshape(-1, k)
+    assert bool(((dist - ref).abs() <= rtol * ref.abs().clamp(min=1.0))[ok].all()), "distance value off"
+
+
+def assert_lists_differ_only_at_ties(ids_a, ids_b, query, corpus, metric, rtol=2e-5):
+    """Two id lists for one query (ours / the oracle's or the reference's): either identical, or of the same length
+    with the same fp64 distance profile -- i.e. they differ only in WHICH of several (near-)equidistant candidates
+    they name (torch.topk's tie order is unspecified; fp32 summation order moves near-ties)."""
+    ids_a, ids_b = [int(i) for i in ids_a], [int(i) for i in ids_b]
+    if ids_a == ids_b:
+        return True
+    assert len(ids_a) == len(ids_b), (ids_a, ids_b)
+    q = np.asarray(query, dtype=np.float64)
+
+    def d64(ids):
+        c = np.asarray(corpus[ids], dtype=np.float64)
+        if metric == "l2":
+            return np.sqrt((((q - c) + 1e-6) ** 2).sum(1))
+        return 1.0 - (c @ q) / np.maximum(np.linalg.norm(c, axis=1) * np.linalg.norm(q), 1e-8)
+    da, db = d64(ids_a), d64(ids_b)
+    assert np.all(np.abs(da - db) <= rtol * np.maximum(1.0, np.abs(db))), "id lists differ beyond a distance tie"
+    return False

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import G, cases, check_topk_against_candidates, dev, make_hashing
+from helpers import assert_lists_differ_only_at_ties, G, cases, check_topk_against_candidates, dev, make_hashing
 from nlsh_amd import synth
 from oracle import oracle
 
@@ -186,7 +186,10 @@ def test_scan_golden_injected_keys(name, algo):
         _, d64 = oracle.distances(queries[q], corpus, rows, meta["metric"], f64=True)
         check_topk_against_candidates(idx[q], dist[q], rows, d64, meta["k"])
     rec = oracle.calculate_recall(list(g[name + "/ground_truth"]), res)
-    assert abs(np.mean(rec) - meta["mean_recall"]) <= 1.0 / (meta["k"] * meta["Q"]) * 3
+    # every list was shown above to equal the reference's up to k-th-distance ties: recall can move by at most the
+    # number of ids those ties substituted
+    swapped = sum(len(set(res[q]) - set(meta["result_ids"][q])) for q in range(meta["Q"]))
+    assert abs(np.mean(rec) - meta["mean_recall"]) <= swapped / (meta["k"] * meta["Q"]) + 1e-12
 
 
 SCAN_CASES = [
@@ -237,8 +240,11 @@ def test_scan_vs_oracle_shapes(metric, d, N, Q, H, k, seg, P, algo):
         rows = np.concatenate([i2r.get(kk, np.zeros(0, np.int32)) for kk in key_lists[q]]) if key_lists[q] else np.zeros(0, np.int32)
         _, d64 = oracle.distances(queries[q], corpus, rows, metric, f64=True)
         check_topk_against_candidates(idx[q], dist[q], rows, d64, k)
-        exact += int(np.array_equal(idx[q], oi[q]))
-    assert exact >= 0.9 * Q                                       # id lists identical to the oracle except near-ties
+        n = min(k, int(onc[q]))
+        exact += int(assert_lists_differ_only_at_ties(idx[q][:n], oi[q][:n], queries[q], corpus, metric))
+        assert np.all(idx[q][n:] == -1)
+    if algo == "tiled" and metric == "l2":                        # same k-ascending fmaf chain as the oracle: no near-ties to move
+        assert exact == Q
 
 
 def test_hash_times_100_keys_and_sliced_scan():
@@ -309,14 +315,21 @@ def test_task_table_overflow_is_detected_and_retried():
     Ws, bs = synth.make_weights([d, 64, H], seed=3)
     hashing = make_hashing(d, (64,), H, Ws, bs)
     indexer = Indexer(hashing, dev(corpus), SIFT.distance, seg_rows=64)
-    for algo in (0, 1):
-        indexer._max_tasks[algo] = 5                                # far too small: must grow, not truncate
+    for algo in (0, 1, 2):
+        indexer._max_tasks[(algo, 80, 1)] = 5                       # far too small: must grow, not truncate
     ids, nc = indexer.query(dev(queries), k=10, hash_times=1)
-    assert indexer._max_tasks[indexer.last_algo] > 5
+    assert indexer._max_tasks[(indexer.last_algo, 80, 1)] > 5
+    # the device-resident form detects it too (check=True) and a batch of another shape gets its own table
+    indexer._max_tasks[(indexer.last_algo, 80, 1)] = 5
+    _, i2, n2, _ = indexer.query_tensors(dev(queries), k=10, hash_times=1)
+    assert n2.cpu().tolist() == nc and indexer._max_tasks[(indexer.last_algo, 80, 1)] > 5
+    ids40, nc40 = indexer.query(dev(queries[:40]), k=10, hash_times=1)
+    assert ids40 == ids[:40] and nc40 == nc[:40] and (indexer.last_algo, 40, 1) in indexer._max_tasks
     ox = oracle.OracleIndexer(Ws, bs, corpus)
     oids, onc = ox.query(queries, k=10, hash_times=1)
     assert nc == onc
-    assert sum(a == b for a, b in zip(ids, oids)) >= 76
+    for q, (a, b) in enumerate(zip(ids, oids)):
+        assert_lists_differ_only_at_ties(a, b, queries[q], corpus, "l2")
 
 
 # ----------------------------------------------------------------------------- end to end (config 0)

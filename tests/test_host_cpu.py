@@ -137,3 +137,24 @@ def test_reference_import_paths_resolve_to_the_hip_package():
         "print('ok')\n") % os.path.join(ROOT, "neural-locality-sensitive-hashing_amd", "compat")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-2000:]
+
+
+def test_bench_gpus_n_launches_n_ranks_or_fails(tmp_path):
+    """`python bench.py --gpus 2` (no launcher, no WORLD_SIZE) must start 2 ranks itself; a world size that disagrees
+    with --gpus is an error, never a 1-GPU run under an N-GPU label.  --rehearse-launch stops after the rendezvous
+    (gloo), so this runs without a GPU; the full 2-rank run is tests/test_gpu_distributed.py."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    bench = os.path.join(ROOT, "bench.py")
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--rehearse-launch"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2
+    bad = subprocess.run([sys.executable, bench, "--gpus", "2", "--rehearse-launch"], env=dict(env, WORLD_SIZE="3", RANK="0"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "disagrees" in bad.stderr
+    one = subprocess.run([sys.executable, bench, "--gpus", "1", "--rehearse-launch"], env=env, capture_output=True, text=True, timeout=120)
+    assert one.returncode == 0 and json.loads(one.stdout.splitlines()[-1])["n_gpus"] == 1

@@ -58,3 +58,47 @@ def test_checkpoint_loaders_npz_statedict_torchscript(tmp_path):
     assert torch.allclose(y, ref, atol=1e-5)
     with pytest.raises(ValueError):
         nio.weights_from_state_dict({"foo.weight": np.zeros((2, 2))})
+
+
+def test_dataset_classes_read_the_path_they_are_given(tmp_path):
+    """nlsh/data.py:14-46,112-140: `SIFT(path, unit_norm)` / `Glove(path, unit_norm, unit_ball)` load THAT file (TEXMEX
+    directory here; ann-benchmarks HDF5 needs h5py) and never substitute generated data."""
+    import pytest
+    from nlsh_amd import data, io
+    rng = np.random.default_rng(0)
+    base = rng.integers(0, 200, size=(300, 16)).astype(np.float32)
+    query = rng.integers(0, 200, size=(20, 16)).astype(np.float32)
+    gt = rng.integers(0, 300, size=(20, 10)).astype(np.int32)
+    d = tmp_path / "sift"
+    d.mkdir()
+    io.write_vecs(str(d / "sift_base.fvecs"), base)
+    io.write_vecs(str(d / "sift_query.fvecs"), query)
+    io.write_vecs(str(d / "sift_groundtruth.ivecs"), gt)
+    ds = data.SIFT(str(d), unit_norm=True)
+    with pytest.raises(ValueError):
+        ds.training                                   # not prepared (nlsh/data.py:142-144)
+    ds.load()
+    mean, std = base.mean(0), base.std(0)
+    assert ds.prepared and ds.dim == 16
+    assert np.allclose(ds.training, (base - mean) / std, atol=1e-6) and np.allclose(ds.testing, (query - mean) / std, atol=1e-6)
+    assert np.array_equal(ds.ground_truth, gt)
+    with pytest.raises(AttributeError):
+        ds.training_self_knn                          # no train_knn in the dataset
+    io.write_vecs(str(d / "sift_train_knn.ivecs"), gt[:, :5])
+    g = data.Glove(str(d), unit_ball=True)
+    g.load()
+    assert np.allclose(np.linalg.norm(g.training, axis=1), 1.0, atol=1e-5) and g.training_self_knn.shape == (20, 5)
+    assert data.metric_of(data.SIFT.distance) == "l2" and data.metric_of(g.distance) == "cosine"
+    with pytest.raises(ValueError):
+        data.SIFT(None)
+    with pytest.raises(FileNotFoundError):
+        data.SIFT(str(tmp_path / "missing.hdf5")).load()
+    (tmp_path / "fake.hdf5").write_bytes(b"not hdf5")
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError):
+            data.SIFT(str(tmp_path / "fake.hdf5")).load()
+    syn = data.SyntheticSIFT(n_train=500, n_test=10, dim=32, k=5, unit_norm=True, with_train_knn=True)
+    syn.load()
+    assert syn.training.shape == (500, 32) and syn.ground_truth.shape == (10, 5) and syn.training_self_knn.shape == (500, 5)

@@ -187,3 +187,48 @@ def test_sampled_probes_track_probabilities():
             if code not in seen:
                 seen.append(code)
         assert list(keys[r, :n[r]]) == seen
+
+
+# ----------------------------------------------------------------------------- CPU-baseline forms of the scan
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine"])
+@pytest.mark.parametrize("d", [128, 100, 25])
+def test_simd_scan_is_bit_identical_to_the_scalar_oracle(metric, d):
+    """bench.py's cpu_baseline times the AVX2 form (8 candidates per lane set); it must be the SAME computation."""
+    rng = np.random.default_rng(d)
+    N, Q, P, k = 6000, 120, 4, 10
+    corpus = rng.standard_normal((N, d)).astype(np.float32)
+    corpus[10:40] = corpus[3000:3030]                                        # exact ties
+    queries = rng.standard_normal((Q, d)).astype(np.float32)
+    perm, uniq, offs = oracle.build_csr(rng.integers(0, 60, N))
+    qk, nk = rng.integers(0, 64, (Q, P)), rng.integers(0, P + 1, Q).astype(np.int32)
+    a = oracle.query_batch(corpus, perm, uniq, offs, queries, qk, nk, k, metric)
+    b = oracle.query_batch(corpus, perm, uniq, offs, queries, qk, nk, k, metric, simd=True)
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine"])
+def test_torch_restatement_agrees_with_the_oracle(metric):
+    """oracle/torch_restatement.py (nlsh/indexer.py:56-96 on torch-CPU ops) vs the C oracle: same candidate counts,
+    same id lists wherever the k-th distance is not tied (torch.topk's tie order is unspecified, F11), F7 lists."""
+    import torch
+    from oracle import torch_restatement as tr
+    rng = np.random.default_rng(5)
+    d, N, Q, P, k = 64, 5000, 80, 4, 10
+    corpus = rng.standard_normal((N, d)).astype(np.float32)
+    queries = rng.standard_normal((Q, d)).astype(np.float32)
+    perm, uniq, offs = oracle.build_csr(rng.integers(0, 300, N))
+    qk, nk = rng.integers(0, 320, (Q, P)), rng.integers(0, P + 1, Q).astype(np.int32)
+    od, oi, nc = oracle.query_batch(corpus, perm, uniq, offs, queries, qk, nk, k, metric)
+    lists = [qk[i, :nk[i]].tolist() for i in range(Q)]
+    res, ncs = tr.query(torch.from_numpy(corpus), tr.build_index2row(perm, uniq, offs), torch.from_numpy(queries), lists, k, metric)
+    assert ncs == nc.tolist()
+    full = [q for q in range(Q) if nc[q] >= k]
+    assert len(full) > 20 and all(res[q] == oi[q].tolist() for q in full)
+    i2r = {int(key): perm[offs[i]:offs[i + 1]].tolist() for i, key in enumerate(uniq)}
+    for q in range(Q):
+        if nc[q] < k:
+            assert res[q] == (i2r.get(int(lists[q][-1]), []) if lists[q] else [])

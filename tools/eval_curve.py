@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--n", type=int, default=0)
     ap.add_argument("--q", type=int, default=10000)
     ap.add_argument("--tanh", action="store_true")
+    ap.add_argument("--seed", type=int, default=1, help="Philox seed of the probes: one stream, so the probe sets are nested in n_samples")
     args = ap.parse_args()
     from nlsh_amd import io as nio, synth
     from nlsh_amd.data import Glove, SIFT, brute_force_topk
@@ -66,7 +67,7 @@ def main():
     for n_samples in range(1, min(args.max_samples, 100) + 1):   # eval.py:148 range(1, 101)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        dist, idx, nc, _ = indexer.query_tensors(qg, k=args.k, hash_times=n_samples, seed=n_samples)
+        dist, idx, nc, _ = indexer.query_tensors(qg, k=args.k, hash_times=n_samples, seed=args.seed)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         ids = [r[r >= 0].tolist() for r in idx.cpu().numpy()]
