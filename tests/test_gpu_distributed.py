@@ -83,3 +83,23 @@ def test_two_rank_sharded_pipeline_equals_single_index(tmp_path, shard):
             assert np.array_equal(got[f"{tag}{i}_0"], dist_.cpu().numpy()), (tag, i)
             assert np.array_equal(got[f"{tag}{i}_2"], nc_.cpu().numpy()), (tag, i)
     assert 0.4 * len(corpus) < int(got["rows"][0]) < 0.6 * len(corpus)
+
+
+def test_bench_gpus_2_self_launch_reports_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts the two ranks itself (rehearsal mode: gloo
+    rendezvous, both ranks on cuda:0 since the box has one GPU) and rank 0 prints ONE JSON line with n_gpus == 2."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(NLSH_BENCH_SAME_DEVICE="1", NLSH_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--n", "60000", "--q", "1000", "--steps", "3", "--warmup", "1",
+           "--batches", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["value"] > 0 and rec["device_resident_qps"] > 0
+    assert rec["scaling"] == "strong" and 0 <= rec["recall_at_10"] <= 1
+    assert rec["roofline"]["frac"] <= 1.0 and rec["roofline"]["bound"] in ("valu", "hbm")
+    assert "sharded x2" in rec["config"]["parallelism"]
