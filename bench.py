@@ -64,8 +64,8 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="sift1m", choices=["sift1m", "glove"],
                     help="sift1m = BASELINE.json configs[1] (headline); glove = configs[2] (1,183,514 x 100-d, cosine, 24-bit)")
-    ap.add_argument("--n", type=int, default=int(os.environ.get("NLSH_BENCH_N", 0)))
-    ap.add_argument("--q", type=int, default=int(os.environ.get("NLSH_BENCH_Q", 10_000)))
+    ap.add_argument("--rows", "--n", dest="n", type=int, default=int(os.environ.get("NLSH_BENCH_N", 0)))
+    ap.add_argument("--queries", "--q", dest="q", type=int, default=int(os.environ.get("NLSH_BENCH_Q", 10_000)))
     ap.add_argument("--batches", type=int, default=4, help="distinct query batches the timed steps rotate over")
     ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--hash-size", type=int, default=0)
@@ -96,8 +96,12 @@ def _free_port():
 
 def self_launch(args):
     """--gpus N > 1 without a launcher: run the N ranks as a torchrun child (this process has made no GPU call)."""
+    # torchrun's own parser prefix-matches options that FOLLOW the script path (`--n` reads as an ambiguous --nnodes /
+    # --nproc-per-node): hand the short spellings over in their long form
+    long_form = {"--n": "--rows", "--q": "--queries"}
+    argv = [long_form.get(a, a) for a in sys.argv[1:]]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     return subprocess.call(cmd, env=env)
 
