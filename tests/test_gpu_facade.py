@@ -132,7 +132,7 @@ def test_untagged_distance_callable_takes_the_generic_path(metric):
     sizes = {kk: len(v) for kk, v in fused.index2row.items()}
     small_key = min(sizes, key=sizes.get)
     if sizes[small_key] < k:
-        generic.hash = lambda *a, **kw: [[small_key, absent]] * Q
+        generic.hash = lambda *a, **kw: [[small_key, absent]] * 4
         ids_e, nc_e = generic.query(qg[:4], k=k, hash_times=2)
         assert ids_e == [[]] * 4 and nc_e == [sizes[small_key]] * 4
         res_e, nc_e2, _, _ = fused.query_with_keys(qg[:4], [[small_key, absent]] * 4, k=k)
