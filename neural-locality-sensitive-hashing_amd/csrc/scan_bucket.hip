@@ -21,6 +21,8 @@
 //   bscan2 | bscan3: partial top-k per (task, query)
 //   bmerge   wave/query: merge the partial lists of its (probe, segment) pairs -> final top-k
 // Results do not depend on slot/task order: every list is merged with the (distance, id) comparator.
+#include <stdlib.h>
+
 #include "scan_common.h"
 
 // Diagnostic build only (make EXTRA=-DNLSH_SCAN_TRACE, tools/scan_trace.py): wave 0 of every bscan3 workgroup
@@ -44,6 +46,10 @@ extern "C" int nlsh_debug_scan_trace(float *host, int n_floats) {
 
 #ifndef NLSH_FAT_STAGES
 #define NLSH_FAT_STAGES 1
+#endif
+
+#ifndef NLSH_FAST_KBLOCK
+#define NLSH_FAST_KBLOCK 1  // hand-scheduled k-blocks for full L2 tasks (0: compiler-scheduled loop everywhere, for A/B)
 #endif
 
 #ifndef NLSH_ABLATE
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(256) void binit_kernel(BArgs a) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < a.Q) a.tauq[i] = KEY_NONE;
     if (i < a.nb) a.bcount[i] = 0;
-    if (i < 4) a.counters[i] = 0;
+    if (i < 8) a.counters[i] = 0;   // task-queue cursors of the persistent tiled scan (one per XCD)
     if (i < 2) a.status[i] = 0;
 }
 
@@ -421,6 +427,95 @@ __device__ __forceinline__ void apply_qchunk(const QChunk<QW> &qc, const float4 
     }
 }
 
+// ---- hand-scheduled k-block of a FULL L2 task (4 queries per wave x 4 row tiles x 4 chunks) ------------------------------
+// r02 finding (ISA + SQ counters of the compiler-scheduled loop): every (tile, query) block sat behind two or three
+// uniform branches and an `s_waitcnt lgkmcnt(0)` placed directly after its `ds_read_b128` -- the LDS round trip was exposed
+// 16 times per chunk step and the scalar loads of the next chunk (same counter) were waited for as soon as they were
+// issued; waves spent as many cycles stalled at issue as executing.  Full tasks are 29 % of the tasks and most of the
+// arithmetic, so their k-blocks run this straight-line form instead: VALU in inline asm (the compiler cannot re-order or
+// re-guard it), the row chunk of tile t+1 and the query chunk c+1 requested one block (48 VALU) ahead, no branches.
+// Same arithmetic in the same order as apply_qchunk: (q - c) + eps, fmaf chain in ascending k -> bit-identical results.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// eps is the 32-bit LITERAL, not an SGPR: tools/probe_l2_block.hip measured 2.2 cycles per VALU for this block with the
+// literal against 2.9-3.4 with eps in an SGPR (a VALU instruction that reads an SGPR issues slower on gfx950: sub/add
+// with SGPR operands only, 4.1 cycles) -- only the v_sub reads one (the query value).
+__device__ __forceinline__ void l2_query_block(float &a, const float4 r, const f32x4 q) {
+    float t0, t1, t2, t3;
+    asm volatile(
+        "v_sub_f32 %[t0], %[q0], %[r0]\n\t"
+        "v_sub_f32 %[t1], %[q1], %[r1]\n\t"
+        "v_sub_f32 %[t2], %[q2], %[r2]\n\t"
+        "v_sub_f32 %[t3], %[q3], %[r3]\n\t"
+        "v_add_f32 %[t0], 0x358637bd, %[t0]\n\t"
+        "v_add_f32 %[t1], 0x358637bd, %[t1]\n\t"
+        "v_add_f32 %[t2], 0x358637bd, %[t2]\n\t"
+        "v_add_f32 %[t3], 0x358637bd, %[t3]\n\t"
+        "v_fmac_f32 %[a], %[t0], %[t0]\n\t"
+        "v_fmac_f32 %[a], %[t1], %[t1]\n\t"
+        "v_fmac_f32 %[a], %[t2], %[t2]\n\t"
+        "v_fmac_f32 %[a], %[t3], %[t3]"
+        : [a] "+v"(a), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+        : [r0] "v"(r.x), [r1] "v"(r.y), [r2] "v"(r.z), [r3] "v"(r.w), [q0] "s"(q.x), [q1] "s"(q.y), [q2] "s"(q.z), [q3] "s"(q.w));
+}
+
+struct QSet { f32x4 v[4]; };   // one 16-byte chunk of each of the wave's 4 queries: 16 SGPRs
+
+// four s_load_dwordx4 the compiler can neither merge into wider loads (x8 pairs cost 64 SGPRs for a double buffer and
+// spilled) nor move: the caller waits for them with s_waitcnt lgkmcnt(0) before the first VALU block that reads them
+// `after`: a VGPR the loads pretend to read -- the row chunk the NEXT VALU block consumes.  LDS and scalar loads share
+// one counter and scalar loads return out of order, so any wait for LDS data also waits for scalar loads in flight: the
+// compiler's wait for that row chunk is thereby placed BEFORE these loads are issued, and they get a whole 48-VALU
+// block of cover before the next wait.
+__device__ __forceinline__ void load_qset(QSet &q, const const_f32p (&qk)[4], int byte_off, float after) {
+    asm volatile("s_load_dwordx4 %0, %4, %8\n\t"
+                 "s_load_dwordx4 %1, %5, %8\n\t"
+                 "s_load_dwordx4 %2, %6, %8\n\t"
+                 "s_load_dwordx4 %3, %7, %8"
+                 : "=&s"(q.v[0]), "=&s"(q.v[1]), "=&s"(q.v[2]), "=&s"(q.v[3])
+                 : "s"(qk[0]), "s"(qk[1]), "s"(qk[2]), "s"(qk[3]), "n"(byte_off), "v"(after));
+}
+
+__device__ __forceinline__ void l2_tile_block(float (&acc)[4], const float4 r, const QSet &q) {
+    l2_query_block(acc[0], r, q.v[0]);
+    l2_query_block(acc[1], r, q.v[1]);
+    l2_query_block(acc[2], r, q.v[2]);
+    l2_query_block(acc[3], r, q.v[3]);
+}
+
+// one k-block of KB = 4 chunks, 4 tiles, 4 queries; RS = 5 float4 slots per LDS row
+__device__ __forceinline__ void l2_full_kblock(const float4 *col, const const_f32p (&qk)[4], float (&acc)[4][4]) {
+    constexpr int RS = NLSH_TILED_KB + 1, TS = 64 * RS;   // tile stride in float4 slots
+    static_assert(NLSH_TILED_KB == 4, "the hand-scheduled k-block is written for 4 chunks");
+    QSet qa, qb;
+    float4 ra, rb;
+    ra = col[0];
+    load_qset(qa, qk, 0, 0.0f);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#define NLSH_STEP(C, QCUR, QNEXT, HAS_NEXT)                                  \
+    rb = col[TS + (C)];                                                      \
+    if (HAS_NEXT) load_qset(QNEXT, qk, 16 * ((C) + 1), ra.x);                \
+    __builtin_amdgcn_sched_barrier(0);                                       \
+    l2_tile_block(acc[0], ra, QCUR);                                         \
+    ra = col[2 * TS + (C)];                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                       \
+    l2_tile_block(acc[1], rb, QCUR);                                         \
+    rb = col[3 * TS + (C)];                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                       \
+    l2_tile_block(acc[2], ra, QCUR);                                         \
+    if (HAS_NEXT) ra = col[(C) + 1];                                         \
+    __builtin_amdgcn_sched_barrier(0);                                       \
+    l2_tile_block(acc[3], rb, QCUR);                                         \
+    if (HAS_NEXT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         \
+    __builtin_amdgcn_sched_barrier(0);
+    NLSH_STEP(0, qa, qb, true)
+    NLSH_STEP(1, qb, qa, true)
+    NLSH_STEP(2, qa, qb, true)
+    NLSH_STEP(3, qb, qa, false)
+#undef NLSH_STEP
+}
+
 // QW queries per wave, NW waves per workgroup (QW*NW queries per task), TPS 64-row tiles per task.
 // k-blocks of KB chunks are the OUTER loop: one stage holds the KB-chunk slice of ALL 64*TPS rows of
 // the segment in LDS, so every scalar-loaded query chunk is applied to TPS row tiles (TPS x fewer
@@ -518,6 +613,10 @@ __global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
 #pragma unroll
             for (int jq = 0; jq < QW; ++jq) qk[jq] = qs[jq] + kb * KBt * 4;
             const float4 *col = tile + lane * RSt;
+            if (NLSH_FAST_KBLOCK && METRIC == NLSH_METRIC_L2_EPS && QW == 4 && TPS == 4 && nqw == 4 && ntile == 4 && nchunk == 4) {
+                l2_full_kblock(col, qk, acc);
+                continue;
+            }
             QChunk<QW> qa, qb;
             load_qchunk<QW, false>(qa, qk, nqw, 0);
             for (int c = 0; c < nchunk; c += 2) {
@@ -595,6 +694,240 @@ __global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------ persistent tiled variant
+// Same task, same arithmetic, same partial lists as bscan3_kernel; what changes is WHO runs a task and WHEN its
+// operands are fetched.  r01's trace of the one-shot kernel: a workgroup spends ~15 us before its first fma (a chain
+// of dependent global loads: task count -> descriptor -> query ids -> first row slice -> first query chunk) and 45 %
+// of the summed workgroup time is such per-task fixed cost.  Here a FIXED grid of resident workgroups (CUs x
+// occupancy) walks the size-ordered task list with stride gridDim.x and software-pipelines ACROSS tasks:
+//   * the next task's descriptor is requested (scalar load) when the current task starts;
+//   * during the current task's LAST k-block the next task's query ids are requested (scalar loads) and its first
+//     row slice is issued into the staging registers that the k-block pipeline would otherwise leave idle;
+//   * the top-k selection of the current task therefore runs while those loads are in flight, and the next task
+//     starts with everything it needs already on the way: no dependent round trip is exposed after the first task.
+// Task ids keep the chunked XCD map of the one-shot kernel (16 consecutive ids per XCD per round), so the query groups
+// of one row segment still meet in one XCD's L2.  Exit: every wave of a workgroup sees the same task count and the
+// same stride, so all waves leave the loop in the same iteration (no barrier is skipped by a subset of waves).
+typedef const __attribute__((address_space(4))) int32_t *const_i32p;
+
+// SGPR budget: the loop keeps in scalar registers only what the distance loop and the task switch need (task ids as
+// 32-bit ints, the next task as its raw descriptor + query ids); everything the epilogue needs (gid, inv_norm, tauq,
+// partial, k) is re-read from the kernel-argument segment THROUGH A POINTER THE COMPILER CANNOT SEE THROUGH, so those
+// loads are not hoisted out of the loop and kept live across it (hoisted they cost ~100 SGPR spills = VALU
+// v_writelane/v_readlane traffic and 11 more VGPRs: 6 instead of 7 waves per SIMD).
+template <int METRIC, int QW, int NW, int TPS>
+__global__ __launch_bounds__(64 * NW) void bscan3p_kernel(BArgs a_) {
+    constexpr int NT = 64 * NW;
+    constexpr int KB = NLSH_TILED_KB;
+    constexpr int ROWS = 64 * TPS;
+    constexpr int SPT = ROWS * KB / NT;
+    constexpr int RPP = NT / KB;
+    constexpr int RS = KB + 1;
+    __shared__ float4 tile[ROWS * RS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    typedef const __attribute__((address_space(4))) BArgs *const_args_p;
+    const_args_p ap = (const_args_p)__builtin_amdgcn_kernarg_segment_ptr();   // BArgs is the only kernel parameter: offset 0
+    int ntasks;
+    {
+        long long n = ap->status[0];
+        if (n > ap->max_tasks) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) ap->status[1] = 1;  // incomplete: caller must retry
+            n = ap->max_tasks;
+        }
+        ntasks = (int)n;   // task ids fit 31 bits (the host clamps max_tasks to 2^31 - 8)
+    }
+    // Dynamic task queue, one cursor per XCD (workgroup b runs on XCD b % 8): the c-th task an XCD takes is
+    // ((c / 16) * 8 + xcd) * 16 + c % 16 -- the chunked map of the one-shot kernel (16 consecutive ids per XCD), walked
+    // front to back by each XCD at its own pace.  A static stride instead (task = slot + i * gridDim) measured 0.447 ms
+    // against 0.355 ms for the one-shot kernel: a workgroup's ~8 tasks differ in cost and nothing evens them out.
+    // Ids are claimed TWO tasks ahead by thread 0 (returning atomic, ~2 us) and handed to the other waves through one
+    // LDS word across the k-block barriers, so no wave ever waits for the atomic.
+    constexpr int XC = 16;
+    __shared__ int next_id[2];
+    const int xcd = blockIdx.x & 7;
+    int *cursor = ap->counters + xcd;
+    auto task_of = [&](int c) { return ((c / XC) * 8 + xcd) * XC + (c % XC); };
+    if (tid == 0) {
+        next_id[0] = task_of(atomicAdd(cursor, 1));
+        next_id[1] = task_of(atomicAdd(cursor, 1));
+    }
+    __syncthreads();
+    int t = __builtin_amdgcn_readfirstlane(next_id[0]);
+    int t_n = __builtin_amdgcn_readfirstlane(next_id[1]);
+    if (t >= ntasks) return;
+    int claim = 0;   // thread 0: the id claimed for the task after next (in flight during the current task)
+
+    const int d4 = ap->d4p;
+    auto load_desc = [&](int tt) {   // one s_load_dwordx4
+        const const_i32p p = (const_i32p)ap->task + 4ll * tt;
+        return make_int4(p[0], p[1], p[2], p[3]);
+    };
+    auto load_qids = [&](const int4 desc, int (&qid)[QW]) {   // scalar loads; queries dealt round-robin over the waves
+        const const_i32p p = (const_i32p)ap->inv_q + desc.x;
+        int nqw = (desc.y - wave + NW - 1) / NW;
+        nqw = nqw < 0 ? 0 : (nqw > QW ? QW : nqw);
+#pragma unroll
+        for (int jq = 0; jq < QW; ++jq) qid[jq] = p[jq < nqw ? wave + NW * jq : 0];
+    };
+    auto kshift_of = [](int nrows) {
+        const int ntile = (nrows + 63) >> 6;
+        return NLSH_FAT_STAGES ? (ntile <= 1 ? 2 : (ntile == 2 ? 1 : 0)) : 0;
+    };
+    float4 stg[SPT];
+    auto stage_load = [&](int row0, int nrows, int kshift, int kb) {
+        const float4 *corpus4 = reinterpret_cast<const float4 *>(ap->corpus);
+        const long long stride4 = ap->row_stride >> 2;
+        const int KBt = KB << kshift, RPPt = RPP >> kshift;
+        const int sc = tid & (KBt - 1), sr = tid / KBt;
+        const int gc = kb * KBt + sc;
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) {
+            const int r = sr + RPPt * i;
+            stg[i] = (r < nrows && gc < d4) ? corpus4[(long long)(row0 + r) * stride4 + gc] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+
+    [[maybe_unused]] const unsigned long long tr0 = SCAN_NOW();
+    [[maybe_unused]] unsigned long long tr_stage = 0, tr_comp = 0, tr_epi = 0, tr_sw = 0, tr_tasks = 0, tr_lists = 0;
+    int4 desc = load_desc(t), desc_n = make_int4(0, 0, 0, 0);
+    int qid[QW], qid_n[QW];
+    load_qids(desc, qid);
+    bool has_next = t_n < ntasks;
+    if (has_next) desc_n = load_desc(t_n);
+    stage_load(desc.z, desc.w, kshift_of(desc.w), 0);
+
+    for (;;) {
+        asm volatile("" : "+s"(ap));   // opaque: argument loads below this point are not hoisted above the loop
+        const int row0 = __builtin_amdgcn_readfirstlane(desc.z), nrows = __builtin_amdgcn_readfirstlane(desc.w);
+        const int ntile = (nrows + 63) >> 6, kshift = kshift_of(nrows);
+        int nqw = (__builtin_amdgcn_readfirstlane(desc.y) - wave + NW - 1) / NW;
+        nqw = nqw < 0 ? 0 : (nqw > QW ? QW : nqw);
+        const int KBt = KB << kshift, RSt = KBt + 1, RPPt = RPP >> kshift;
+        const int nkb = (d4 + KBt - 1) / KBt;
+        const int sc = tid & (KBt - 1), sr = tid / KBt;
+        float acc[TPS][QW];
+#pragma unroll
+        for (int tl = 0; tl < TPS; ++tl)
+#pragma unroll
+            for (int jq = 0; jq < QW; ++jq) acc[tl][jq] = 0.0f;
+        const const_f32p qbase = (const_f32p)ap->qpad;
+        const int qstride = (int)ap->qpad_stride;   // Q * stride < 2^31 floats (Q < 2^31 / 1024 is checked by the host)
+
+        if (has_next && tid == 0) claim = atomicAdd(cursor, 1);   // id of the task after next; consumed at the end of this task
+        for (int kb = 0; kb < nkb; ++kb) {
+            [[maybe_unused]] const unsigned long long ta = SCAN_NOW();
+            __syncthreads();  // everyone has finished reading the previous k-block (or the previous task's last one)
+#pragma unroll
+            for (int i = 0; i < SPT; ++i) tile[(sr + RPPt * i) * RSt + sc] = stg[i];
+            __syncthreads();
+            [[maybe_unused]] const unsigned long long tb = SCAN_NOW();
+            tr_stage += tb - ta;
+            if (kb + 1 < nkb) {
+                stage_load(row0, nrows, kshift, kb + 1);  // in flight while this k-block is computed
+            } else if (has_next) {                         // last k-block: the NEXT task's first slice rides the idle staging registers
+                load_qids(desc_n, qid_n);
+                stage_load(desc_n.z, desc_n.w, kshift_of(desc_n.w), 0);
+            }
+            if (nqw > 0) {
+                const int nchunk = min(KBt, d4 - kb * KBt);
+                const_f32p qk[QW];
+#pragma unroll
+                for (int jq = 0; jq < QW; ++jq) qk[jq] = qbase + ((long long)__builtin_amdgcn_readfirstlane(qid[jq]) * qstride + kb * KBt * 4);
+                const float4 *col = tile + lane * RSt;
+                QChunk<QW> qa, qb;
+                load_qchunk<QW, false>(qa, qk, nqw, 0);
+                for (int c = 0; c < nchunk; c += 2) {
+                    const bool has1 = c + 1 < nchunk;
+                    load_qchunk<QW, false>(qb, qk, nqw, has1 ? c + 1 : c);
+#pragma unroll
+                    for (int tl = 0; tl < TPS; ++tl)
+                        if (tl < ntile) apply_qchunk<METRIC, QW, false>(qa, col[tl * 64 * RSt + c], nqw, acc[tl]);
+                    if (!has1) break;
+                    load_qchunk<QW, false>(qa, qk, nqw, c + 2 < nchunk ? c + 2 : c);
+#pragma unroll
+                    for (int tl = 0; tl < TPS; ++tl)
+                        if (tl < ntile) apply_qchunk<METRIC, QW, false>(qb, col[tl * 64 * RSt + c + 1], nqw, acc[tl]);
+                }
+            }
+#ifdef NLSH_SCAN_TRACE
+            {
+                float sink = 0.f;
+#pragma unroll
+                for (int tl = 0; tl < TPS; ++tl)
+#pragma unroll
+                    for (int jq = 0; jq < QW; ++jq) sink += acc[tl][jq];
+                asm volatile("" ::"v"(sink));
+                tr_comp += SCAN_NOW() - tb;
+            }
+#endif
+        }
+        [[maybe_unused]] const unsigned long long te0 = SCAN_NOW();
+        // epilogue of the current task (the next task's first slice and query ids are in flight meanwhile)
+        if (nqw > 0) {
+            asm volatile("" : "+s"(ap));
+            const int32_t *gidp = ap->gid;
+            const float *invp = ap->inv_norm;
+            unsigned long long *tauq = ap->tauq;
+            uint64_t *partial = ap->partial;
+            const int k = ap->k;
+            int32_t mygid[TPS];
+            float myinv[TPS];
+            bool valid[TPS];
+#pragma unroll
+            for (int tl = 0; tl < TPS; ++tl) {
+                valid[tl] = tl * 64 + lane < nrows;
+                const int prow = row0 + (valid[tl] ? tl * 64 + lane : 0);
+                mygid[tl] = valid[tl] ? gidp[prow] : -1;
+                myinv[tl] = (METRIC == NLSH_METRIC_COSINE && valid[tl]) ? invp[prow] : 0.0f;
+            }
+#pragma unroll
+            for (int jq = 0; jq < QW; ++jq) {
+                if (jq < nqw) {
+                    const uint64_t tau_g = global_tau_load(tauq + qid[jq]);
+                    uint64_t key[TPS];
+#pragma unroll
+                    for (int tl = 0; tl < TPS; ++tl) {
+                        const float dist = finish_distance<METRIC>(acc[tl][jq], myinv[tl]);
+                        const uint64_t kk = valid[tl] ? make_key(dist, mygid[tl]) : KEY_NONE;
+                        key[tl] = kk < tau_g ? kk : KEY_NONE;
+                    }
+                    uint64_t *out = partial + ((long long)t * (QW * NW) + wave + NW * jq) * k;
+                    const uint64_t bound = select_k_smallest<TPS>(key, k, lane, out);
+                    if (bound != KEY_NONE && lane == 0) atomicMin(tauq + qid[jq], (unsigned long long)bound);
+                }
+            }
+        }
+#ifdef NLSH_SCAN_TRACE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tr_epi += SCAN_NOW() - te0;
+        tr_tasks += 1;
+        tr_lists += nqw;
+#endif
+        [[maybe_unused]] const unsigned long long ts0 = SCAN_NOW();
+        if (!has_next) break;
+        // hand the claimed id to the other waves: written before, read after the barriers of the next task's first k-block
+        // (all waves have read the previous value long ago: it was consumed right after THIS task's first barrier pair)
+        if (tid == 0) next_id[0] = task_of(claim);
+        t = t_n;
+        desc = desc_n;
+#pragma unroll
+        for (int jq = 0; jq < QW; ++jq) qid[jq] = qid_n[jq];
+        __syncthreads();
+        t_n = __builtin_amdgcn_readfirstlane(next_id[0]);
+        has_next = t_n < ntasks;
+        if (has_next) desc_n = load_desc(t_n);
+        tr_sw += SCAN_NOW() - ts0;
+    }
+#ifdef NLSH_SCAN_TRACE
+    if (lane == 0 && blockIdx.x * 4 + wave < NLSH_TRACE_SLOTS) {
+        float *o = g_scan_trace + (blockIdx.x * 4 + wave) * 8;
+        o[0] = (float)(SCAN_NOW() - tr0); o[1] = (float)tr_stage; o[2] = (float)tr_comp; o[3] = (float)tr_epi;
+        o[4] = (float)tr_sw; o[5] = (float)tr_tasks; o[6] = (float)tr_lists; o[7] = (float)(tr0 & 0xFFFFFFull);
+    }
+#endif
+}
+
 __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
     const int lane = threadIdx.x & 63;
     const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -659,6 +992,38 @@ constexpr int TILED_QB = NLSH_TILED_QB;  // queries per task of the tiled schedu
 #endif
 constexpr int TILED_TPS = NLSH_TILED_TPS;  // 64-row tiles per task of the tiled schedule (segment = 64*TPS rows)
 
+// NLSH_TILED_VARIANT (environment, diagnostic A/B only): 0 = one-shot workgroups (r01), 1 = persistent (default)
+static int tiled_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("NLSH_TILED_VARIANT");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+
+// resident workgroups of the persistent kernel on the current device: CUs x occupancy, a multiple of 128
+static unsigned persistent_grid(int metric) {
+    static unsigned g[2] = {0, 0};
+    unsigned &r = g[metric == NLSH_METRIC_L2_EPS ? 0 : 1];
+    if (r == 0) {
+        int dev = 0, cus = 256, occ = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (metric == NLSH_METRIC_L2_EPS)
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, bscan3p_kernel<NLSH_METRIC_L2_EPS, 4, TILED_QB / 4, TILED_TPS>, 64 * (TILED_QB / 4), 0);
+        else
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, bscan3p_kernel<NLSH_METRIC_COSINE, 4, TILED_QB / 4, TILED_TPS>, 64 * (TILED_QB / 4), 0);
+        if (occ < 1) occ = 4;
+        const char *e = getenv("NLSH_TILED_OCC");   // diagnostic: cap the resident workgroups per CU
+        if (e && atoi(e) > 0 && atoi(e) < occ) occ = atoi(e);
+        unsigned n = (unsigned)cus * (unsigned)occ;
+        n = n / 128 * 128;
+        r = n < 128 ? 128 : n;
+    }
+    return r;
+}
+
 struct BWs {
     size_t pbkt, prec, inv_q, bcount, pairoff, taskoff, bgroups, counters, btot, task, partial, qpad, tauq, total;
 };
@@ -672,7 +1037,7 @@ static void blayout(long long Q, int P, int k, long long max_tasks, long long nb
     w->pairoff = o;  o += ws_align(nb4);
     w->taskoff = o;  o += ws_align(nb4);
     w->bgroups = o;  o += ws_align(nb4);
-    w->counters = o; o += ws_align(16);
+    w->counters = o; o += ws_align(64);
     w->btot = o;     o += ws_align((size_t)((nb + 255) / 256 + 1) * 8);
     w->task = o;     o += ws_align((size_t)max_tasks * sizeof(int4));
     w->partial = o;  o += ws_align((size_t)max_tasks * (tiled ? TILED_QB : 8) * k * 8);
@@ -721,7 +1086,7 @@ int bucket_scan_run(const BucketScanCall &c) {
     hipStream_t s = c.stream;
     if (c.phases & NLSH_PHASE_PLAN) {
         long long n_init = c.Q > c.nb ? c.Q : c.nb;
-        if (n_init < 4) n_init = 4;
+        if (n_init < 8) n_init = 8;
         hipLaunchKernelGGL(binit_kernel, dim3((unsigned)((n_init + 255) / 256)), dim3(256), 0, s, a);
         const unsigned gp = (unsigned)((c.Q * c.P + 255) / 256);
         int stride = 1;
@@ -738,10 +1103,18 @@ int bucket_scan_run(const BucketScanCall &c) {
     if ((c.phases & NLSH_PHASE_SCAN) && c.max_tasks > 0) {
         if (c.ev_begin) NLSH_CHECK_HIP(hipEventRecord((hipEvent_t)c.ev_begin, s));
         if (c.tiled) {
-            const unsigned grid = (unsigned)((c.max_tasks + 127) / 128 * 128);  // one workgroup per task (the chunked XCD map works on 8 x 16 ids)
             // QW = 4 queries per wave (SGPR budget: two chunks x QW x 4 scalar values in flight), NW = 4 waves
-            if (c.metric == NLSH_METRIC_L2_EPS) hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_L2_EPS, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
-            else hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_COSINE, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
+            if (tiled_variant() == 0) {   // one-shot workgroups (r01): one per task, the chunked XCD map works on 8 x 16 ids
+                const unsigned grid = (unsigned)((c.max_tasks + 127) / 128 * 128);
+                if (c.metric == NLSH_METRIC_L2_EPS) hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_L2_EPS, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
+                else hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_COSINE, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
+            } else {                       // persistent workgroups: CUs x occupancy, rounded to the XCD map's 128
+                const unsigned resident = persistent_grid(c.metric);
+                const unsigned need = (unsigned)((c.max_tasks + 127) / 128 * 128);
+                const unsigned grid = need < resident ? need : resident;
+                if (c.metric == NLSH_METRIC_L2_EPS) hipLaunchKernelGGL((bscan3p_kernel<NLSH_METRIC_L2_EPS, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
+                else hipLaunchKernelGGL((bscan3p_kernel<NLSH_METRIC_COSINE, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
+            }
         } else {
             const unsigned grid = (unsigned)((c.max_tasks + 3) / 4);  // one wavefront per task
             if (c.metric == NLSH_METRIC_L2_EPS) launch_bscan2<NLSH_METRIC_L2_EPS>(a, d4, grid, s);

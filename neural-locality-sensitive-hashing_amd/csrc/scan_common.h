@@ -83,13 +83,31 @@ __device__ __forceinline__ void global_tau_publish(unsigned long long *p, uint64
     if (kth != KEY_NONE && lane == 0) atomicMin(p, (unsigned long long)kth + 1ull);
 }
 
+// wave-wide min / max of a u32 (every lane gets the result): DPP row operations, no LDS, no scalar ALU
+template <bool MAX>
+__device__ __forceinline__ uint32_t wave_minmax_u32(uint32_t x) {
+    auto op = [](uint32_t a, uint32_t b) { return MAX ? (a > b ? a : b) : (a < b ? a : b); };
+    const uint32_t id = MAX ? 0u : 0xFFFFFFFFu;
+    x = op(x, (uint32_t)__builtin_amdgcn_update_dpp((int)id, (int)x, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    x = op(x, (uint32_t)__builtin_amdgcn_update_dpp((int)id, (int)x, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    x = op(x, (uint32_t)__builtin_amdgcn_update_dpp((int)id, (int)x, 0x141, 0xF, 0xF, false));  // row_half_mirror
+    x = op(x, (uint32_t)__builtin_amdgcn_update_dpp((int)id, (int)x, 0x140, 0xF, 0xF, false));  // row_mirror -> 16-lane result
+    x = op(x, (uint32_t)__builtin_amdgcn_update_dpp((int)id, (int)x, 0x142, 0xA, 0xF, false));  // row_bcast15 into rows 1 and 3
+    x = op(x, (uint32_t)__builtin_amdgcn_update_dpp((int)id, (int)x, 0x143, 0xC, 0xF, false));  // row_bcast31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+
 // k smallest of the wave's NK*64 keys (NK per lane, KEY_NONE = absent), written UNSORTED to out[0..k)
-// (KEY_NONE padded), without any ordered insertion: a 32-step bisection on the distance word finds
-// the k-th distance with ballots + scalar popcounts (one short dependent chain per step instead of
-// ~350 cycles per inserted key), exact-distance ties are cut by a second bisection on the id word,
-// and the survivors are compacted with mbcnt prefix counts.  Returns the exclusive bound to publish
-// for the query ((d_k + 1) << 32, every key above it is beyond this list's k-th best) or KEY_NONE
-// when the list holds fewer than k keys.
+// (KEY_NONE padded), without any ordered insertion.  A bisection on the distance word looks for ANY threshold that
+// separates exactly k keys (ballots + scalar popcounts): it starts from the [min, max] bracket of the present
+// distances (two DPP reductions) and stops as soon as a pivot has exactly k keys at or below it -- with 256 keys
+// spread over the bracket that takes ~9 steps instead of the 32 a search for the exact k-th value needs.  This matters
+// because a step is ~17 scalar-ALU instructions and a CU has ONE scalar unit for its four SIMDs (r02 ablation: with the
+// 32-step form the selection was HALF of the tiled scan's time, 95 M of its SALU instructions per launch).  Exact
+// distance ties at the k-th place (no pivot separates k keys) fall back to the exact search plus a second bisection
+// on the id word.  Survivors are compacted with mbcnt prefix counts.  Returns an exclusive upper bound of this list's
+// k-th best key to publish for the query (every key at or above it is beyond the list's k best) or KEY_NONE when the
+// list holds fewer than k keys.
 template <int NK>
 __device__ __forceinline__ uint64_t select_k_smallest(const uint64_t (&key)[NK], int k, int lane, uint64_t *out) {
     uint32_t hi[NK], lo[NK];
@@ -102,32 +120,45 @@ __device__ __forceinline__ uint64_t select_k_smallest(const uint64_t (&key)[NK],
     }
     uint32_t dk = 0xFFFFFFFFu, idk = 0xFFFFFFFFu;  // take everything present (hi of a present key < 0xFFFFFFFF)
     if (n >= k) {
-        uint32_t a = 0, b = 0xFFFFFFFEu;
-        while (a < b) {  // smallest d with #{hi <= d} >= k
+        uint32_t mn = hi[0], mx = hi[0] == 0xFFFFFFFFu ? 0u : hi[0];
+#pragma unroll
+        for (int i = 1; i < NK; ++i) {
+            mn = hi[i] < mn ? hi[i] : mn;
+            const uint32_t h = hi[i] == 0xFFFFFFFFu ? 0u : hi[i];
+            mx = h > mx ? h : mx;
+        }
+        uint32_t a = wave_minmax_u32<false>(mn), b = wave_minmax_u32<true>(mx);
+        // invariants: #{hi <= b} >= k (b = max: all n > k keys) and #{hi < a} < k (a = min: none)
+        bool split = false;
+        if (n == k) { a = b; split = true; }   // all present keys are taken: the cut is the largest of them
+        while (a < b) {
             const uint32_t mid = a + ((b - a) >> 1);
             int cnt = 0;
 #pragma unroll
             for (int i = 0; i < NK; ++i) cnt += __popcll(__ballot(hi[i] <= mid));
-            if (cnt >= k) b = mid; else a = mid + 1;
+            if (cnt == k) { a = mid; split = true; break; }   // exactly k keys at or below the pivot: done
+            if (cnt > k) b = mid; else a = mid + 1;
         }
         dk = a;
-        int c_less = 0, c_eq = 0;
+        if (!split) {   // a == b = the k-th distance, shared by keys on both sides of the cut (or n has exactly k at/below max)
+            int c_less = 0, c_eq = 0;
 #pragma unroll
-        for (int i = 0; i < NK; ++i) {
-            c_less += __popcll(__ballot(hi[i] < dk));
-            c_eq += __popcll(__ballot(hi[i] == dk));
-        }
-        const int need = k - c_less;  // >= 1 keys to take among those at distance d_k
-        if (c_eq > need) {            // exact distance ties: smallest ids win
-            a = 0; b = 0xFFFFFFFFu;
-            while (a < b) {
-                const uint32_t mid = a + ((b - a) >> 1);
-                int cnt = 0;
-#pragma unroll
-                for (int i = 0; i < NK; ++i) cnt += __popcll(__ballot(hi[i] == dk && lo[i] <= mid));
-                if (cnt >= need) b = mid; else a = mid + 1;
+            for (int i = 0; i < NK; ++i) {
+                c_less += __popcll(__ballot(hi[i] < dk));
+                c_eq += __popcll(__ballot(hi[i] == dk));
             }
-            idk = a;
+            const int need = k - c_less;  // >= 1 keys to take among those at distance d_k
+            if (c_eq > need) {            // exact distance ties: smallest ids win
+                a = 0; b = 0xFFFFFFFFu;
+                while (a < b) {
+                    const uint32_t mid = a + ((b - a) >> 1);
+                    int cnt = 0;
+#pragma unroll
+                    for (int i = 0; i < NK; ++i) cnt += __popcll(__ballot(hi[i] == dk && lo[i] <= mid));
+                    if (cnt >= need) b = mid; else a = mid + 1;
+                }
+                idk = a;
+            }
         }
     }
     int base = 0;

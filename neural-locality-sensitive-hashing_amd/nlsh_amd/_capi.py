@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "lib", "libnlsh_hip.so")
+LIB_PATH = os.environ.get("NLSH_HIP_LIB") or os.path.join(_PKG, "lib", "libnlsh_hip.so")   # override: diagnostic builds only
 CSRC = os.path.join(_PKG, "csrc")
 
 OK, E_INVALID, E_UNSUPPORTED, E_HIP, E_WORKSPACE = 0, -1, -2, -3, -4

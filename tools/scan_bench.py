@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Kernel-iteration harness for the candidate scan: builds the headline index once (SIFT1M-shaped, learned 16-bit hash),
+then times the scan phase alone (HIP events around the scan kernel, as bench.py does) and the whole device-resident
+step, and checks the result against the query-major schedule (ids equal up to fp32 near-ties, candidate counts exact).
+
+    python tools/scan_bench.py [--algo tiled] [--iters 30] [--workload sift1m|glove]
+    NLSH_TILED_VARIANT=0 python tools/scan_bench.py      # r01 one-shot workgroups, for A/B
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "neural-locality-sensitive-hashing_amd")):
+    sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from nlsh_amd import io, synth  # noqa: E402
+from nlsh_amd.data import Glove, SIFT  # noqa: E402
+from nlsh_amd.indexer import Indexer  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--algo", default="tiled")
+    ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--workload", default="sift1m")
+    ap.add_argument("--rows", type=int, default=0)
+    ap.add_argument("--queries", type=int, default=10_000)
+    ap.add_argument("--tag", default="")
+    ap.add_argument("--no-check", action="store_true")
+    args = ap.parse_args()
+    Q = args.queries
+    if args.workload == "sift1m":
+        N, d = args.rows or 1_000_000, 128
+        corpus_h, mean, std = synth.standardise(synth.sift_manifold(N, d, seed=synth.SEED_DATA))
+        queries_h, _, _ = synth.standardise(synth.sift_manifold(Q, d, seed=synth.SEED_QUERY), mean, std)
+        ck, dist_fn, compat = "sift1m_manifold_h16.npz", SIFT.distance, True
+    else:
+        N, d = args.rows or 1_183_514, 100
+        corpus_h, queries_h = synth.glove_manifold(N, d, seed=synth.SEED_DATA), synth.glove_manifold(Q, d, seed=synth.SEED_QUERY)
+        ck, dist_fn, compat = "glove_manifold_h24.npz", Glove.distance, False
+    Ws, bs = io.load_hasher_weights(os.path.join(ROOT, "neural-locality-sensitive-hashing_amd", "checkpoints", ck))
+    hashing = io.hashing_from_weights(Ws, bs, compat=compat)
+    cg, qg = torch.from_numpy(corpus_h).cuda(), torch.from_numpy(queries_h).cuda()
+    ix = Indexer(hashing, cg, dist_fn, compat=compat, algo=args.algo)
+    keys, nkeys = ix.hash_device(qg, hash_times=10, seed=7)
+    ix.scan_tensors(qg, keys, nkeys, k=10)                      # sizes the task table
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.iters)]
+    for a, b in evs:
+        a.record(); b.record()
+    for _ in range(3):
+        ix.scan_tensors(qg, keys, nkeys, k=10, check=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.iters):
+        out = ix.scan_tensors(qg, keys, nkeys, k=10, check=False, events=evs[i])
+    torch.cuda.synchronize()
+    scan_call_ms = 1e3 * (time.perf_counter() - t0) / args.iters
+    kern = np.array([a.elapsed_time(b) for a, b in evs])
+    t0 = time.perf_counter()
+    for i in range(args.iters):
+        ix.query_tensors(qg, k=10, hash_times=10, seed=7, check=False)
+    torch.cuda.synchronize()
+    step_ms = 1e3 * (time.perf_counter() - t0) / args.iters
+    dist, idx, nc, _ = out
+    rec = {"tag": args.tag, "variant": os.environ.get("NLSH_TILED_VARIANT", "default"), "algo": args.algo,
+           "scan_kernel_ms": float(kern.mean()), "scan_kernel_ms_min": float(kern.min()), "scan_phases_ms": scan_call_ms,
+           "step_ms": step_ms, "tasks": int(ix.last_status.cpu()[0]), "sum_candidates": int(nc.long().sum())}
+    if not args.no_check:
+        ref = Indexer(hashing, cg, dist_fn, compat=compat, algo="query")
+        d0, i0, n0, _ = ref.scan_tensors(qg, keys, nkeys, k=10)
+        rec["ncand_equal"] = bool(torch.equal(n0, nc))
+        rec["ids_equal_frac"] = float((i0 == idx).all(1).float().mean())
+        both = (i0 >= 0) & (idx >= 0)
+        rec["max_abs_dist_diff"] = float((d0 - dist).abs()[both].max())
+    print(json.dumps(rec), flush=True)
+
+
+if __name__ == "__main__":
+    main()
