@@ -459,61 +459,121 @@ __device__ __forceinline__ void l2_query_block(float &a, const float4 r, const f
         : [r0] "v"(r.x), [r1] "v"(r.y), [r2] "v"(r.z), [r3] "v"(r.w), [q0] "s"(q.x), [q1] "s"(q.y), [q2] "s"(q.z), [q3] "s"(q.w));
 }
 
-struct QSet { f32x4 v[4]; };   // one 16-byte chunk of each of the wave's 4 queries: 16 SGPRs
+struct QSet { f32x4 v[4]; };   // one 16-byte chunk of each of the wave's (up to) 4 queries: 16 SGPRs
 
-// four s_load_dwordx4 the compiler can neither merge into wider loads (x8 pairs cost 64 SGPRs for a double buffer and
-// spilled) nor move: the caller waits for them with s_waitcnt lgkmcnt(0) before the first VALU block that reads them
+// NQ s_load_dwordx4 (query pointer + byte offset in an SGPR) that the compiler can neither merge into wider loads (x8
+// pairs need 64 SGPRs for a double buffer and spilled) nor move; the caller waits for them with s_waitcnt lgkmcnt(0)
+// before the first VALU block that reads them.
 // `after`: a VGPR the loads pretend to read -- the row chunk the NEXT VALU block consumes.  LDS and scalar loads share
 // one counter and scalar loads return out of order, so any wait for LDS data also waits for scalar loads in flight: the
-// compiler's wait for that row chunk is thereby placed BEFORE these loads are issued, and they get a whole 48-VALU
-// block of cover before the next wait.
+// compiler's wait for that row chunk is thereby placed BEFORE these loads are issued, and they get a whole VALU block
+// of cover before the next wait.
+template <int NQ>
 __device__ __forceinline__ void load_qset(QSet &q, const const_f32p (&qk)[4], int byte_off, float after) {
-    asm volatile("s_load_dwordx4 %0, %4, %8\n\t"
-                 "s_load_dwordx4 %1, %5, %8\n\t"
-                 "s_load_dwordx4 %2, %6, %8\n\t"
-                 "s_load_dwordx4 %3, %7, %8"
-                 : "=&s"(q.v[0]), "=&s"(q.v[1]), "=&s"(q.v[2]), "=&s"(q.v[3])
-                 : "s"(qk[0]), "s"(qk[1]), "s"(qk[2]), "s"(qk[3]), "n"(byte_off), "v"(after));
+    if (NQ == 4)
+        asm volatile("s_load_dwordx4 %0, %4, %8\n\ts_load_dwordx4 %1, %5, %8\n\ts_load_dwordx4 %2, %6, %8\n\ts_load_dwordx4 %3, %7, %8"
+                     : "=&s"(q.v[0]), "=&s"(q.v[1]), "=&s"(q.v[2]), "=&s"(q.v[3])
+                     : "s"(qk[0]), "s"(qk[1]), "s"(qk[2]), "s"(qk[3]), "s"(byte_off), "v"(after));
+    else if (NQ == 3)
+        asm volatile("s_load_dwordx4 %0, %3, %6\n\ts_load_dwordx4 %1, %4, %6\n\ts_load_dwordx4 %2, %5, %6"
+                     : "=&s"(q.v[0]), "=&s"(q.v[1]), "=&s"(q.v[2])
+                     : "s"(qk[0]), "s"(qk[1]), "s"(qk[2]), "s"(byte_off), "v"(after));
+    else if (NQ == 2)
+        asm volatile("s_load_dwordx4 %0, %2, %4\n\ts_load_dwordx4 %1, %3, %4"
+                     : "=&s"(q.v[0]), "=&s"(q.v[1])
+                     : "s"(qk[0]), "s"(qk[1]), "s"(byte_off), "v"(after));
+    else
+        asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(q.v[0]) : "s"(qk[0]), "s"(byte_off), "v"(after));
 }
 
+template <int NQ>
 __device__ __forceinline__ void l2_tile_block(float (&acc)[4], const float4 r, const QSet &q) {
-    l2_query_block(acc[0], r, q.v[0]);
-    l2_query_block(acc[1], r, q.v[1]);
-    l2_query_block(acc[2], r, q.v[2]);
-    l2_query_block(acc[3], r, q.v[3]);
+#pragma unroll
+    for (int jq = 0; jq < NQ; ++jq) l2_query_block(acc[jq], r, q.v[jq]);
 }
 
-// one k-block of KB = 4 chunks, 4 tiles, 4 queries; RS = 5 float4 slots per LDS row
-__device__ __forceinline__ void l2_full_kblock(const float4 *col, const const_f32p (&qk)[4], float (&acc)[4][4]) {
-    constexpr int RS = NLSH_TILED_KB + 1, TS = 64 * RS;   // tile stride in float4 slots
-    static_assert(NLSH_TILED_KB == 4, "the hand-scheduled k-block is written for 4 chunks");
+// One k-block (nchunk 16-byte chunks of every row, LDS row stride RSt slots) for a wave that holds NQ queries, on NT
+// 64-row tiles.  Blocks = (chunk, tile) pairs in chunk-major order; two chunks are unrolled so that the row-chunk
+// registers (rr[0], rr[1]) and the query sets (qa, qb) alternate statically: block j reads rr[j & 1] while the row
+// chunk of block j + 1 is on its way into rr[(j + 1) & 1], and the query chunk c + 1 is requested during the first block
+// of chunk c.
+template <int NQ, int NT>
+__device__ __forceinline__ void l2_kblock(const float4 *col, int RSt, int nchunk, const const_f32p (&qk)[4], float (&acc)[4][4]) {
     QSet qa, qb;
-    float4 ra, rb;
-    ra = col[0];
-    load_qset(qa, qk, 0, 0.0f);
+    float4 rr[2];
+    const int TS = 64 * RSt;   // tile stride in float4 slots
+    rr[0] = col[0];
+    load_qset<NQ>(qa, qk, 0, 0.0f);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-#define NLSH_STEP(C, QCUR, QNEXT, HAS_NEXT)                                  \
-    rb = col[TS + (C)];                                                      \
-    if (HAS_NEXT) load_qset(QNEXT, qk, 16 * ((C) + 1), ra.x);                \
-    __builtin_amdgcn_sched_barrier(0);                                       \
-    l2_tile_block(acc[0], ra, QCUR);                                         \
-    ra = col[2 * TS + (C)];                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                       \
-    l2_tile_block(acc[1], rb, QCUR);                                         \
-    rb = col[3 * TS + (C)];                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                       \
-    l2_tile_block(acc[2], ra, QCUR);                                         \
-    if (HAS_NEXT) ra = col[(C) + 1];                                         \
-    __builtin_amdgcn_sched_barrier(0);                                       \
-    l2_tile_block(acc[3], rb, QCUR);                                         \
-    if (HAS_NEXT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         \
-    __builtin_amdgcn_sched_barrier(0);
-    NLSH_STEP(0, qa, qb, true)
-    NLSH_STEP(1, qb, qa, true)
-    NLSH_STEP(2, qa, qb, true)
-    NLSH_STEP(3, qb, qa, false)
-#undef NLSH_STEP
+    for (int c = 0; c < nchunk; c += 2) {
+        const bool has1 = c + 1 < nchunk, has2 = c + 2 < nchunk;
+#pragma unroll
+        for (int j = 0; j < 2 * NT; ++j) {
+            const int tl = j % NT, cc = j / NT;             // compile-time after unrolling
+            if (cc == 1 && tl == 0 && !has1) break;        // odd chunk count: the pair's second chunk does not exist
+            const int jn = j + 1, tn = jn % NT, cn = jn / NT;
+            if (cn == 0 || (cn == 1 && has1) || (cn == 2 && has2)) rr[jn & 1] = col[tn * TS + c + cn];
+            if (tl == 0) {
+                if (cc == 0 && has1) load_qset<NQ>(qb, qk, 16 * (c + 1), rr[j & 1].x);
+                if (cc == 1 && has2) load_qset<NQ>(qa, qk, 16 * (c + 2), rr[j & 1].x);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            l2_tile_block<NQ>(acc[tl], rr[j & 1], cc ? qb : qa);
+            if (tl == NT - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the next chunk's queries (and first row chunk)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// All k-blocks of one L2 task for a wave that holds NQ (0..4) of its queries, NTL = tiles of the task (1..4): staging
+// (global -> registers -> LDS, next k-block's loads in flight during the current one) + the hand-scheduled k-blocks.
+// The (NQ, NTL) pair is chosen ONCE per task, outside the k-block loop: chosen per k-block, the 16 accumulators crossed
+// a 16-way switch every k-block and the register allocator copied all of them in and out each time (466 v_mov in the
+// kernel, +67 % instructions on small shapes).  NTL also fixes the fat-stage geometry at compile time.
+template <int NW, int NQ, int NTL>
+__device__ __forceinline__ void l2_task(float4 *tile, const float4 *corpus4, long long stride4, int d4, int row0, int nrows,
+                                        const const_f32p (&qs)[4], int tid, int lane, float (&acc)[4][4]) {
+    constexpr int NTH = 64 * NW, KB = NLSH_TILED_KB;
+    constexpr int kshift = NLSH_FAT_STAGES ? (NTL <= 1 ? 2 : (NTL == 2 ? 1 : 0)) : 0;
+    constexpr int KBt = KB << kshift, RSt = KBt + 1, RPPt = (NTH / KB) >> kshift, SPT = 256 * KB / NTH;
+    const int nkb = (d4 + KBt - 1) / KBt;
+    const int sc = tid & (KBt - 1), sr = tid / KBt;   // staging map: KBt threads cover 16*KBt contiguous bytes of a row
+    float4 stg[SPT];
+    auto stage_load = [&](int kb) {
+        const int gc = kb * KBt + sc;
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) {
+            const int r = sr + RPPt * i;
+            stg[i] = (r < nrows && gc < d4) ? corpus4[(long long)(row0 + r) * stride4 + gc] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    stage_load(0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        __syncthreads();  // everyone has finished reading the previous k-block
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) tile[(sr + RPPt * i) * RSt + sc] = stg[i];
+        __syncthreads();
+        if (kb + 1 < nkb) stage_load(kb + 1);  // in flight while this k-block is computed
+        if (NQ > 0) {
+            const int nchunk = min(KBt, d4 - kb * KBt);
+            const_f32p qk[4];
+#pragma unroll
+            for (int jq = 0; jq < 4; ++jq) qk[jq] = qs[jq] + kb * KBt * 4;
+            l2_kblock<(NQ > 0 ? NQ : 1), NTL>(tile + lane * RSt, RSt, nchunk, qk, acc);
+        }
+    }
+}
+
+template <int NW, int NQ>
+__device__ __forceinline__ void l2_task_nt(int ntile, float4 *tile, const float4 *corpus4, long long stride4, int d4, int row0, int nrows,
+                                           const const_f32p (&qs)[4], int tid, int lane, float (&acc)[4][4]) {
+    switch (ntile) {
+        case 1: l2_task<NW, NQ, 1>(tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc); break;
+        case 2: l2_task<NW, NQ, 2>(tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc); break;
+        case 3: l2_task<NW, NQ, 3>(tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc); break;
+        default: l2_task<NW, NQ, 4>(tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc); break;
+    }
 }
 
 // QW queries per wave, NW waves per workgroup (QW*NW queries per task), TPS 64-row tiles per task.
@@ -596,9 +656,19 @@ __global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
 #pragma unroll
         for (int jq = 0; jq < QW; ++jq) acc[tl][jq] = 0.0f;
 
-    stage_load(0);
+    constexpr bool FAST = NLSH_FAST_KBLOCK && NLSH_ABLATE == 0 && METRIC == NLSH_METRIC_L2_EPS && QW == 4 && TPS == 4;
+    if (FAST) {   // hand-scheduled form, specialised per (queries of this wave, tiles of the task); same barrier count on every path
+        switch (nqw) {
+            case 0: l2_task_nt<NW, 0>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc); break;
+            case 1: l2_task_nt<NW, 1>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc); break;
+            case 2: l2_task_nt<NW, 2>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc); break;
+            case 3: l2_task_nt<NW, 3>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc); break;
+            default: l2_task_nt<NW, 4>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc); break;
+        }
+    }
+    if (!FAST) stage_load(0);
     [[maybe_unused]] const unsigned long long ts1 = SCAN_NOW();
-    for (int kb = 0; kb < nkb; ++kb) {
+    for (int kb = 0; !FAST && kb < nkb; ++kb) {
         const unsigned long long ta = SCAN_NOW();
         __syncthreads();  // everyone has finished reading the previous k-block
 #pragma unroll
@@ -613,10 +683,6 @@ __global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
 #pragma unroll
             for (int jq = 0; jq < QW; ++jq) qk[jq] = qs[jq] + kb * KBt * 4;
             const float4 *col = tile + lane * RSt;
-            if (NLSH_FAST_KBLOCK && METRIC == NLSH_METRIC_L2_EPS && QW == 4 && TPS == 4 && nqw == 4 && ntile == 4 && nchunk == 4) {
-                l2_full_kblock(col, qk, acc);
-                continue;
-            }
             QChunk<QW> qa, qb;
             load_qchunk<QW, false>(qa, qk, nqw, 0);
             for (int c = 0; c < nchunk; c += 2) {
@@ -835,6 +901,7 @@ __global__ __launch_bounds__(64 * NW) void bscan3p_kernel(BArgs a_) {
 #pragma unroll
                 for (int jq = 0; jq < QW; ++jq) qk[jq] = qbase + ((long long)__builtin_amdgcn_readfirstlane(qid[jq]) * qstride + kb * KBt * 4);
                 const float4 *col = tile + lane * RSt;
+
                 QChunk<QW> qa, qb;
                 load_qchunk<QW, false>(qa, qk, nqw, 0);
                 for (int c = 0; c < nchunk; c += 2) {
@@ -992,12 +1059,12 @@ constexpr int TILED_QB = NLSH_TILED_QB;  // queries per task of the tiled schedu
 #endif
 constexpr int TILED_TPS = NLSH_TILED_TPS;  // 64-row tiles per task of the tiled schedule (segment = 64*TPS rows)
 
-// NLSH_TILED_VARIANT (environment, diagnostic A/B only): 0 = one-shot workgroups (r01), 1 = persistent (default)
+// NLSH_TILED_VARIANT (environment, diagnostic A/B only): 0 = one-shot workgroups (default), 1 = persistent
 static int tiled_variant() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("NLSH_TILED_VARIANT");
-        v = e ? atoi(e) : 1;
+        v = e ? atoi(e) : 0;
     }
     return v;
 }
