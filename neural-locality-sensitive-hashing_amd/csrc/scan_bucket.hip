@@ -21,8 +21,6 @@
 //   bscan2 | bscan3: partial top-k per (task, query)
 //   bmerge   wave/query: merge the partial lists of its (probe, segment) pairs -> final top-k
 // Results do not depend on slot/task order: every list is merged with the (distance, id) comparator.
-#include <stdlib.h>
-
 #include "scan_common.h"
 
 // Diagnostic build only (make EXTRA=-DNLSH_SCAN_TRACE, tools/scan_trace.py): wave 0 of every bscan3 workgroup
@@ -48,12 +46,25 @@ extern "C" int nlsh_debug_scan_trace(float *host, int n_floats) {
 #define NLSH_FAT_STAGES 1
 #endif
 
+#ifndef NLSH_TILED_MIN_WAVES
+#define NLSH_TILED_MIN_WAVES 1  // min waves per SIMD hint of the tiled kernel (8 = 64 VGPRs / 80 SGPRs: measured equal, 43 SGPR spills)
+#endif
+
+#ifndef NLSH_EPS_VGPR
+#define NLSH_EPS_VGPR 0  // hand-scheduled L2 block: 0 = eps as a 32-bit literal (8-byte v_add), 1 = eps in a VGPR (4-byte)
+#endif
+
+#ifndef NLSH_DEAL_BLOCKS
+#define NLSH_DEAL_BLOCKS 0  // tiled one-shot kernel: 0 = a task's queries dealt round-robin over the 4 waves, 1 = in blocks of 4
+#endif
+#define NLSH_SLOT(wave, jq) (NLSH_DEAL_BLOCKS ? (wave) * QW + (jq) : (wave) + NW * (jq))
+
 #ifndef NLSH_FAST_KBLOCK
 #define NLSH_FAST_KBLOCK 1  // hand-scheduled k-blocks for full L2 tasks (0: compiler-scheduled loop everywhere, for A/B)
 #endif
 
 #ifndef NLSH_ABLATE
-#define NLSH_ABLATE 0  // diagnostic timing builds only: 1 no distance math, 2 no global loads, 3 no top-k, 4 no scalar loads
+#define NLSH_ABLATE 0  // diagnostic timing builds only: 1 no distance math, 2 no global loads, 3 no top-k selection, 4 no scalar loads (generic loop), 5 no epilogue, 6 neither math nor epilogue (staging skeleton)
 #endif
 
 namespace nlsh {
@@ -81,6 +92,7 @@ struct BArgs {
     int32_t *pbkt, *inv_q, *bcount, *pairoff, *taskoff, *bgroups, *counters;
     int4 *prec;  // [Q*P] per (query, probe): {first task of its query group, slot in the group, bucket rows, query groups}; .z = 0: no bucket
     int4 *task;
+    int32_t *task_q;   // tiled schedule: [max_tasks][16] query ids of every task (its group's slice of inv_q, repeated per row segment)
     uint64_t *partial;
     long long max_tasks;
     const int32_t *border;     // [nb] schedule order of the buckets (largest first) or nullptr = CSR order
@@ -98,7 +110,7 @@ __global__ __launch_bounds__(256) void binit_kernel(BArgs a) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < a.Q) a.tauq[i] = KEY_NONE;
     if (i < a.nb) a.bcount[i] = 0;
-    if (i < 8) a.counters[i] = 0;   // task-queue cursors of the persistent tiled scan (one per XCD)
+    if (i < 4) a.counters[i] = 0;
     if (i < 2) a.status[i] = 0;
 }
 
@@ -243,7 +255,17 @@ __global__ __launch_bounds__(256) void bscatter_kernel(BArgs a) {
     // what bmerge needs to find this probe's partial lists, resolved here so that it has one load level less:
     // task of (segment si, group gi) = taskoff + si * ngroups + gi
     const int gi = rel / a.QB;
-    a.prec[idx] = make_int4(a.taskoff[b] + gi, rel - gi * a.QB, a.offsets[b + 1] - a.offsets[b], a.bgroups[b]);
+    const int t0 = a.taskoff[b] + gi, size = a.offsets[b + 1] - a.offsets[b], ng = a.bgroups[b];
+    a.prec[idx] = make_int4(t0, rel - gi * a.QB, size, ng);
+    if (a.task_q) {
+        // the tiled scan reads a task's query ids from the task's own record (address known from the task id alone: the
+        // ids arrive with the descriptor instead of one dependent round trip later); one copy per row segment
+        const int ns = (size + a.seg - 1) / a.seg;
+        for (int si = 0; si < ns; ++si) {
+            const long long tt = (long long)t0 + (long long)si * ng;
+            if (tt < a.max_tasks) a.task_q[tt * a.QB + (rel - gi * a.QB)] = (int32_t)(idx / a.P);
+        }
+    }
 }
 
 // One task: stream `nrows` rows starting at row0 once, score them against the nq <= QB queries of
@@ -442,6 +464,25 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // with SGPR operands only, 4.1 cycles) -- only the v_sub reads one (the query value).
 __device__ __forceinline__ void l2_query_block(float &a, const float4 r, const f32x4 q) {
     float t0, t1, t2, t3;
+#if NLSH_EPS_VGPR
+    float veps = 1e-6f;
+    asm volatile("" : "+v"(veps));   // eps in a VGPR: 4-byte encodings (48 instead of 64 bytes of instruction stream per block)
+    asm volatile(
+        "v_sub_f32 %[t0], %[q0], %[r0]\n\t"
+        "v_sub_f32 %[t1], %[q1], %[r1]\n\t"
+        "v_sub_f32 %[t2], %[q2], %[r2]\n\t"
+        "v_sub_f32 %[t3], %[q3], %[r3]\n\t"
+        "v_add_f32 %[t0], %[e], %[t0]\n\t"
+        "v_add_f32 %[t1], %[e], %[t1]\n\t"
+        "v_add_f32 %[t2], %[e], %[t2]\n\t"
+        "v_add_f32 %[t3], %[e], %[t3]\n\t"
+        "v_fmac_f32 %[a], %[t0], %[t0]\n\t"
+        "v_fmac_f32 %[a], %[t1], %[t1]\n\t"
+        "v_fmac_f32 %[a], %[t2], %[t2]\n\t"
+        "v_fmac_f32 %[a], %[t3], %[t3]"
+        : [a] "+v"(a), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+        : [r0] "v"(r.x), [r1] "v"(r.y), [r2] "v"(r.z), [r3] "v"(r.w), [q0] "s"(q.x), [q1] "s"(q.y), [q2] "s"(q.z), [q3] "s"(q.w), [e] "v"(veps));
+#else
     asm volatile(
         "v_sub_f32 %[t0], %[q0], %[r0]\n\t"
         "v_sub_f32 %[t1], %[q1], %[r1]\n\t"
@@ -457,6 +498,7 @@ __device__ __forceinline__ void l2_query_block(float &a, const float4 r, const f
         "v_fmac_f32 %[a], %[t3], %[t3]"
         : [a] "+v"(a), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
         : [r0] "v"(r.x), [r1] "v"(r.y), [r2] "v"(r.z), [r3] "v"(r.w), [q0] "s"(q.x), [q1] "s"(q.y), [q2] "s"(q.z), [q3] "s"(q.w));
+#endif
 }
 
 struct QSet { f32x4 v[4]; };   // one 16-byte chunk of each of the wave's (up to) 4 queries: 16 SGPRs
@@ -533,7 +575,8 @@ __device__ __forceinline__ void l2_kblock(const float4 *col, int RSt, int nchunk
 // kernel, +67 % instructions on small shapes).  NTL also fixes the fat-stage geometry at compile time.
 template <int NW, int NQ, int NTL>
 __device__ __forceinline__ void l2_task(float4 *tile, const float4 *corpus4, long long stride4, int d4, int row0, int nrows,
-                                        const const_f32p (&qs)[4], int tid, int lane, float (&acc)[4][4]) {
+                                        const const_f32p (&qs)[4], int tid, int lane, float (&acc)[4][4],
+                                        [[maybe_unused]] unsigned long long (&tr)[3]) {
     constexpr int NTH = 64 * NW, KB = NLSH_TILED_KB;
     constexpr int kshift = NLSH_FAT_STAGES ? (NTL <= 1 ? 2 : (NTL == 2 ? 1 : 0)) : 0;
     constexpr int KBt = KB << kshift, RSt = KBt + 1, RPPt = (NTH / KB) >> kshift, SPT = 256 * KB / NTH;
@@ -545,34 +588,43 @@ __device__ __forceinline__ void l2_task(float4 *tile, const float4 *corpus4, lon
 #pragma unroll
         for (int i = 0; i < SPT; ++i) {
             const int r = sr + RPPt * i;
-            stg[i] = (r < nrows && gc < d4) ? corpus4[(long long)(row0 + r) * stride4 + gc] : make_float4(0.f, 0.f, 0.f, 0.f);
+            stg[i] = (NLSH_ABLATE != 2 && r < nrows && gc < d4) ? corpus4[(long long)(row0 + r) * stride4 + gc] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     stage_load(0);
     for (int kb = 0; kb < nkb; ++kb) {
+        [[maybe_unused]] const unsigned long long ta = SCAN_NOW();
         __syncthreads();  // everyone has finished reading the previous k-block
+        [[maybe_unused]] const unsigned long long tb = SCAN_NOW();
 #pragma unroll
         for (int i = 0; i < SPT; ++i) tile[(sr + RPPt * i) * RSt + sc] = stg[i];
         __syncthreads();
         if (kb + 1 < nkb) stage_load(kb + 1);  // in flight while this k-block is computed
-        if (NQ > 0) {
+        [[maybe_unused]] const unsigned long long tc = SCAN_NOW();
+        tr[0] += tb - ta;   // first barrier: the slowest wave's previous k-block
+        tr[1] += tc - tb;   // own stage data (vmcnt) + LDS write + second barrier
+        if (NQ > 0 && NLSH_ABLATE != 1 && NLSH_ABLATE != 6) {
             const int nchunk = min(KBt, d4 - kb * KBt);
             const_f32p qk[4];
 #pragma unroll
             for (int jq = 0; jq < 4; ++jq) qk[jq] = qs[jq] + kb * KBt * 4;
             l2_kblock<(NQ > 0 ? NQ : 1), NTL>(tile + lane * RSt, RSt, nchunk, qk, acc);
+#ifdef NLSH_SCAN_TRACE
+            asm volatile("" : "+v"(acc[0][0]));
+            tr[2] += SCAN_NOW() - tc;
+#endif
         }
     }
 }
 
 template <int NW, int NQ>
 __device__ __forceinline__ void l2_task_nt(int ntile, float4 *tile, const float4 *corpus4, long long stride4, int d4, int row0, int nrows,
-                                           const const_f32p (&qs)[4], int tid, int lane, float (&acc)[4][4]) {
+                                           const const_f32p (&qs)[4], int tid, int lane, float (&acc)[4][4], unsigned long long (&tr)[3]) {
     switch (ntile) {
-        case 1: l2_task<NW, NQ, 1>(tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc); break;
-        case 2: l2_task<NW, NQ, 2>(tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc); break;
-        case 3: l2_task<NW, NQ, 3>(tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc); break;
-        default: l2_task<NW, NQ, 4>(tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc); break;
+        case 1: l2_task<NW, NQ, 1>(tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, tr); break;
+        case 2: l2_task<NW, NQ, 2>(tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, tr); break;
+        case 3: l2_task<NW, NQ, 3>(tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, tr); break;
+        default: l2_task<NW, NQ, 4>(tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, tr); break;
     }
 }
 
@@ -582,47 +634,32 @@ __device__ __forceinline__ void l2_task_nt(int ntile, float4 *tile, const float4
 // scalar loads and SALU per VALU than a tile-outer loop) and the accumulators of all tiles live in
 // registers until the last k-block.  Chunks go through two scalar register sets: the s_loads of
 // chunk c+1 are issued before chunk c is evaluated.
+// One task of the tiled schedule, start to finish (operands of the task already requested by the caller: descriptor and
+// the wave's query ids).  `tile` = the workgroup's LDS stage.
 template <int METRIC, int QW, int NW, int TPS>
-__global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
+__device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, long long t, const int4 desc, const int (&qid_v)[QW], int tid, int lane,
+                                                int wave, [[maybe_unused]] unsigned long long ts_entry) {
     constexpr int NT = 64 * NW;              // threads per workgroup
     constexpr int KB = NLSH_TILED_KB;        // 16-byte chunks per k-block
-    constexpr int RS = KB + 1;               // odd LDS row stride (16-byte slots) -> conflict-free column reads
     constexpr int ROWS = 64 * TPS;
     constexpr int SPT = ROWS * KB / NT;      // staged 16-byte words per thread and stage
     constexpr int RPP = NT / KB;             // rows covered by one pass of the workgroup
-    __shared__ float4 tile[ROWS * RS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    long long ntasks = a.status[0];
-    if (ntasks > a.max_tasks) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) a.status[1] = 1;  // incomplete: caller must retry
-        ntasks = a.max_tasks;
-    }
-    // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Task ids are dealt to the XCDs
-    // in CHUNKS of 16 consecutive ids: the query groups of one row segment (consecutive ids) mostly land on one
-    // XCD and re-read its rows from that L2 instead of HBM, while every XCD still walks the size-ordered task
-    // list front to back (a contiguous 1/8 range per XCD would hand all the heavy tasks to XCD 0).
-    // Placement only changes speed, never results.
-    constexpr int XC = 16;
-    const long long j = blockIdx.x >> 3;
-    const long long t = ((j / XC) * 8 + (blockIdx.x & 7)) * XC + (j % XC);
-    if (t >= ntasks) return;
     [[maybe_unused]] const unsigned long long ts0 = SCAN_NOW();
     [[maybe_unused]] unsigned long long ts_stage = 0, ts_comp = 0;
-    const int4 desc = a.task[t];
     const int pair0 = __builtin_amdgcn_readfirstlane(desc.x);
     const int nq = __builtin_amdgcn_readfirstlane(desc.y);
     const int row0 = __builtin_amdgcn_readfirstlane(desc.z);
     const int nrows = __builtin_amdgcn_readfirstlane(desc.w);  // <= ROWS (the host fixes seg = ROWS)
     // queries are dealt round-robin over the waves (slot = wave + NW*jq): a group of 5 queries costs the
     // workgroup 2 query-times per stage (2,1,1,1) instead of 4 (4,1,0,0); the stage barrier waits for the slowest wave
-    int nqw = (nq - wave + NW - 1) / NW;
+    int nqw = NLSH_DEAL_BLOCKS ? nq - wave * QW : (nq - wave + NW - 1) / NW;
     nqw = __builtin_amdgcn_readfirstlane(nqw < 0 ? 0 : (nqw > QW ? QW : nqw));
 
     const_f32p qs[QW];
     int qid[QW];
 #pragma unroll
     for (int jq = 0; jq < QW; ++jq) {
-        qid[jq] = __builtin_amdgcn_readfirstlane(a.inv_q[pair0 + (jq < nqw ? wave + NW * jq : 0)]);
+        qid[jq] = __builtin_amdgcn_readfirstlane(qid_v[jq]);
         qs[jq] = (const_f32p)(a.qpad + (long long)qid[jq] * a.qpad_stride);
     }
 
@@ -656,14 +693,28 @@ __global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
 #pragma unroll
         for (int jq = 0; jq < QW; ++jq) acc[tl][jq] = 0.0f;
 
-    constexpr bool FAST = NLSH_FAST_KBLOCK && NLSH_ABLATE == 0 && METRIC == NLSH_METRIC_L2_EPS && QW == 4 && TPS == 4;
+    // global row ids (and cosine norms) of the rows this lane owns: requested up front, consumed by the epilogue --
+    // issued there, the load was an exposed round trip at the end of every task (r02 trace: ~2 us of a 28-us task)
+    int32_t mygid[TPS];
+    float myinv[TPS];
+    bool valid[TPS];
+#pragma unroll
+    for (int tl = 0; tl < TPS; ++tl) {
+        valid[tl] = tl * 64 + lane < nrows;
+        const int prow = row0 + (valid[tl] ? tl * 64 + lane : 0);
+        mygid[tl] = valid[tl] ? a.gid[prow] : -1;
+        myinv[tl] = (METRIC == NLSH_METRIC_COSINE && valid[tl]) ? a.inv_norm[prow] : 0.0f;
+    }
+    constexpr bool FAST = NLSH_FAST_KBLOCK && METRIC == NLSH_METRIC_L2_EPS && QW == 4 && TPS == 4;
+    [[maybe_unused]] unsigned long long trl[3] = {0, 0, 0};
+    [[maybe_unused]] const unsigned long long ts_in = SCAN_NOW();
     if (FAST) {   // hand-scheduled form, specialised per (queries of this wave, tiles of the task); same barrier count on every path
         switch (nqw) {
-            case 0: l2_task_nt<NW, 0>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc); break;
-            case 1: l2_task_nt<NW, 1>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc); break;
-            case 2: l2_task_nt<NW, 2>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc); break;
-            case 3: l2_task_nt<NW, 3>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc); break;
-            default: l2_task_nt<NW, 4>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc); break;
+            case 0: l2_task_nt<NW, 0>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
+            case 1: l2_task_nt<NW, 1>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
+            case 2: l2_task_nt<NW, 2>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
+            case 3: l2_task_nt<NW, 3>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
+            default: l2_task_nt<NW, 4>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
         }
     }
     if (!FAST) stage_load(0);
@@ -712,30 +763,28 @@ __global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
     }
     [[maybe_unused]] const unsigned long long ts2 = SCAN_NOW();
     if (nqw == 0) return;
+    if (NLSH_ABLATE == 5 || NLSH_ABLATE == 6) {   // diagnostic: no epilogue at all (the accumulators are kept alive)
+#pragma unroll
+        for (int tl = 0; tl < TPS; ++tl)
+#pragma unroll
+            for (int jq = 0; jq < QW; ++jq) asm volatile("" ::"v"(acc[tl][jq]));
+        return;
+    }
     // lane = row of each tile -> one candidate per lane, tile and query
     // Lists of the same query in other tasks publish their k-th best key to tauq[q] (atomicMin): no
     // candidate above it can reach the final top-k, so it pre-filters this list (fewer insertions).
     // Which partial entries survive depends on timing; the merged result does not.
     // All <= 64*TPS candidates of a list exist at once here (TPS keys per lane), so the k best are
     // SELECTED (bisection + compaction, select_k_smallest) instead of inserted one by one.
-    int32_t mygid[TPS];
-    float myinv[TPS];
-    bool valid[TPS];
-#pragma unroll
-    for (int tl = 0; tl < TPS; ++tl) {
-        valid[tl] = tl * 64 + lane < nrows;
-        const int prow = row0 + (valid[tl] ? tl * 64 + lane : 0);
-        mygid[tl] = valid[tl] ? a.gid[prow] : -1;
-        myinv[tl] = (METRIC == NLSH_METRIC_COSINE && valid[tl]) ? a.inv_norm[prow] : 0.0f;
-    }
-#ifdef NLSH_SCAN_TRACE
-    asm volatile("" ::"v"(mygid[0]));
-#endif
     [[maybe_unused]] const unsigned long long ts3 = SCAN_NOW();
+    // the running bounds of the wave's queries are requested together (one exposed round trip, not one per query)
+    uint64_t tau_w[QW];
+#pragma unroll
+    for (int jq = 0; jq < QW; ++jq) tau_w[jq] = jq < nqw ? global_tau_load(a.tauq + qid[jq]) : KEY_NONE;
 #pragma unroll
     for (int jq = 0; jq < QW; ++jq) {
         if (jq < nqw) {
-            const uint64_t tau_g = global_tau_load(a.tauq + qid[jq]);
+            const uint64_t tau_g = tau_w[jq];
             uint64_t key[TPS];
 #pragma unroll
             for (int tl = 0; tl < TPS; ++tl) {
@@ -743,7 +792,7 @@ __global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
                 const uint64_t kk = valid[tl] ? make_key(dist, mygid[tl]) : KEY_NONE;
                 key[tl] = kk < tau_g ? kk : KEY_NONE;  // beyond another list's k-th best: cannot reach the final top-k
             }
-            uint64_t *out = a.partial + ((long long)t * (QW * NW) + wave + NW * jq) * a.k;
+            uint64_t *out = a.partial + ((long long)t * (QW * NW) + NLSH_SLOT(wave, jq)) * a.k;
             if (NLSH_ABLATE != 3) {
                 const uint64_t bound = select_k_smallest<TPS>(key, a.k, lane, out);
                 if (bound != KEY_NONE && lane == 0) atomicMin(a.tauq + qid[jq], (unsigned long long)bound);
@@ -754,245 +803,51 @@ __global__ __launch_bounds__(64 * NW) void bscan3_kernel(BArgs a) {
     if (tid == 0 && t < NLSH_TRACE_SLOTS) {
         const unsigned long long ts4 = SCAN_NOW();
         float *o = g_scan_trace + t * 8;
-        o[0] = (float)(ts4 - ts0); o[1] = (float)(ts1 - ts0); o[2] = (float)ts_stage; o[3] = (float)ts_comp;
-        o[4] = (float)(ts0 & 0xFFFFFFull); o[5] = (float)(ts4 - ts3); o[6] = (float)nq; o[7] = (float)nrows;
+        o[0] = (float)(ts4 - ts_entry); o[1] = FAST ? (float)(ts_in - ts_entry) : (float)(ts1 - ts0); o[2] = FAST ? (float)trl[0] : (float)ts_stage;
+        o[3] = FAST ? (float)trl[2] : (float)ts_comp;
+        o[4] = FAST ? (float)trl[1] : 0.f; o[5] = (float)(ts4 - ts3); o[6] = (float)(nq * 1000 + nrows); o[7] = (float)(ts_entry & 0xFFFFFFull);
+        // where it ran: HW_ID (wave/simd/cu/sh/se) and XCC_ID, as exact small integers
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        o[2] = (float)(((xcc & 0xF) << 12) | (((hw >> 13) & 0x7) << 9) | (((hw >> 12) & 0x1) << 8) | (((hw >> 8) & 0xF) << 4) | (((hw >> 4) & 0x3) << 2));
+        o[3] = (float)(hw & 0xF);
     }
 #endif
 }
 
-// ------------------------------------------------------------------------------------ persistent tiled variant
-// Same task, same arithmetic, same partial lists as bscan3_kernel; what changes is WHO runs a task and WHEN its
-// operands are fetched.  r01's trace of the one-shot kernel: a workgroup spends ~15 us before its first fma (a chain
-// of dependent global loads: task count -> descriptor -> query ids -> first row slice -> first query chunk) and 45 %
-// of the summed workgroup time is such per-task fixed cost.  Here a FIXED grid of resident workgroups (CUs x
-// occupancy) walks the size-ordered task list with stride gridDim.x and software-pipelines ACROSS tasks:
-//   * the next task's descriptor is requested (scalar load) when the current task starts;
-//   * during the current task's LAST k-block the next task's query ids are requested (scalar loads) and its first
-//     row slice is issued into the staging registers that the k-block pipeline would otherwise leave idle;
-//   * the top-k selection of the current task therefore runs while those loads are in flight, and the next task
-//     starts with everything it needs already on the way: no dependent round trip is exposed after the first task.
-// Task ids keep the chunked XCD map of the one-shot kernel (16 consecutive ids per XCD per round), so the query groups
-// of one row segment still meet in one XCD's L2.  Exit: every wave of a workgroup sees the same task count and the
-// same stride, so all waves leave the loop in the same iteration (no barrier is skipped by a subset of waves).
-typedef const __attribute__((address_space(4))) int32_t *const_i32p;
 
-// SGPR budget: the loop keeps in scalar registers only what the distance loop and the task switch need (task ids as
-// 32-bit ints, the next task as its raw descriptor + query ids); everything the epilogue needs (gid, inv_norm, tauq,
-// partial, k) is re-read from the kernel-argument segment THROUGH A POINTER THE COMPILER CANNOT SEE THROUGH, so those
-// loads are not hoisted out of the loop and kept live across it (hoisted they cost ~100 SGPR spills = VALU
-// v_writelane/v_readlane traffic and 11 more VGPRs: 6 instead of 7 waves per SIMD).
 template <int METRIC, int QW, int NW, int TPS>
-__global__ __launch_bounds__(64 * NW) void bscan3p_kernel(BArgs a_) {
-    constexpr int NT = 64 * NW;
-    constexpr int KB = NLSH_TILED_KB;
+__global__ __launch_bounds__(64 * NW, NLSH_TILED_MIN_WAVES) void bscan3_kernel(BArgs a) {
+    constexpr int NT = 64 * NW;              // threads per workgroup
+    constexpr int KB = NLSH_TILED_KB;        // 16-byte chunks per k-block
+    constexpr int RS = KB + 1;               // odd LDS row stride (16-byte slots) -> conflict-free column reads
     constexpr int ROWS = 64 * TPS;
-    constexpr int SPT = ROWS * KB / NT;
-    constexpr int RPP = NT / KB;
-    constexpr int RS = KB + 1;
+    constexpr int SPT = ROWS * KB / NT;      // staged 16-byte words per thread and stage
+    constexpr int RPP = NT / KB;             // rows covered by one pass of the workgroup
     __shared__ float4 tile[ROWS * RS];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    typedef const __attribute__((address_space(4))) BArgs *const_args_p;
-    const_args_p ap = (const_args_p)__builtin_amdgcn_kernarg_segment_ptr();   // BArgs is the only kernel parameter: offset 0
-    int ntasks;
-    {
-        long long n = ap->status[0];
-        if (n > ap->max_tasks) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) ap->status[1] = 1;  // incomplete: caller must retry
-            n = ap->max_tasks;
-        }
-        ntasks = (int)n;   // task ids fit 31 bits (the host clamps max_tasks to 2^31 - 8)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    [[maybe_unused]] const unsigned long long ts_entry = SCAN_NOW();
+    long long ntasks = a.status[0];
+    if (ntasks > a.max_tasks) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.status[1] = 1;  // incomplete: caller must retry
+        ntasks = a.max_tasks;
     }
-    // Dynamic task queue, one cursor per XCD (workgroup b runs on XCD b % 8): the c-th task an XCD takes is
-    // ((c / 16) * 8 + xcd) * 16 + c % 16 -- the chunked map of the one-shot kernel (16 consecutive ids per XCD), walked
-    // front to back by each XCD at its own pace.  A static stride instead (task = slot + i * gridDim) measured 0.447 ms
-    // against 0.355 ms for the one-shot kernel: a workgroup's ~8 tasks differ in cost and nothing evens them out.
-    // Ids are claimed TWO tasks ahead by thread 0 (returning atomic, ~2 us) and handed to the other waves through one
-    // LDS word across the k-block barriers, so no wave ever waits for the atomic.
+    // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Task ids are dealt to the XCDs
+    // in CHUNKS of 16 consecutive ids: the query groups of one row segment (consecutive ids) mostly land on one
+    // XCD and re-read its rows from that L2 instead of HBM, while every XCD still walks the size-ordered task
+    // list front to back (a contiguous 1/8 range per XCD would hand all the heavy tasks to XCD 0).
+    // Placement only changes speed, never results.
     constexpr int XC = 16;
-    __shared__ int next_id[2];
-    const int xcd = blockIdx.x & 7;
-    int *cursor = ap->counters + xcd;
-    auto task_of = [&](int c) { return ((c / XC) * 8 + xcd) * XC + (c % XC); };
-    if (tid == 0) {
-        next_id[0] = task_of(atomicAdd(cursor, 1));
-        next_id[1] = task_of(atomicAdd(cursor, 1));
-    }
-    __syncthreads();
-    int t = __builtin_amdgcn_readfirstlane(next_id[0]);
-    int t_n = __builtin_amdgcn_readfirstlane(next_id[1]);
+    const long long j = blockIdx.x >> 3;
+    const long long t = ((j / XC) * 8 + (blockIdx.x & 7)) * XC + (j % XC);
+    // the descriptor is requested BEFORE the task count is known (index clamped into the table): one dependent round trip
+    // less in front of every task
+    const long long tc = t < a.max_tasks ? t : a.max_tasks - 1;
+    const int4 desc = a.task[tc];
+    int qid_v[QW];                                    // the task's query ids: address known from the task id alone
+#pragma unroll
+    for (int jq = 0; jq < QW; ++jq) qid_v[jq] = a.task_q[tc * (QW * NW) + NLSH_SLOT(wave, jq)];   // slots >= nq hold garbage, never used
     if (t >= ntasks) return;
-    int claim = 0;   // thread 0: the id claimed for the task after next (in flight during the current task)
-
-    const int d4 = ap->d4p;
-    auto load_desc = [&](int tt) {   // one s_load_dwordx4
-        const const_i32p p = (const_i32p)ap->task + 4ll * tt;
-        return make_int4(p[0], p[1], p[2], p[3]);
-    };
-    auto load_qids = [&](const int4 desc, int (&qid)[QW]) {   // scalar loads; queries dealt round-robin over the waves
-        const const_i32p p = (const_i32p)ap->inv_q + desc.x;
-        int nqw = (desc.y - wave + NW - 1) / NW;
-        nqw = nqw < 0 ? 0 : (nqw > QW ? QW : nqw);
-#pragma unroll
-        for (int jq = 0; jq < QW; ++jq) qid[jq] = p[jq < nqw ? wave + NW * jq : 0];
-    };
-    auto kshift_of = [](int nrows) {
-        const int ntile = (nrows + 63) >> 6;
-        return NLSH_FAT_STAGES ? (ntile <= 1 ? 2 : (ntile == 2 ? 1 : 0)) : 0;
-    };
-    float4 stg[SPT];
-    auto stage_load = [&](int row0, int nrows, int kshift, int kb) {
-        const float4 *corpus4 = reinterpret_cast<const float4 *>(ap->corpus);
-        const long long stride4 = ap->row_stride >> 2;
-        const int KBt = KB << kshift, RPPt = RPP >> kshift;
-        const int sc = tid & (KBt - 1), sr = tid / KBt;
-        const int gc = kb * KBt + sc;
-#pragma unroll
-        for (int i = 0; i < SPT; ++i) {
-            const int r = sr + RPPt * i;
-            stg[i] = (r < nrows && gc < d4) ? corpus4[(long long)(row0 + r) * stride4 + gc] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-
-    [[maybe_unused]] const unsigned long long tr0 = SCAN_NOW();
-    [[maybe_unused]] unsigned long long tr_stage = 0, tr_comp = 0, tr_epi = 0, tr_sw = 0, tr_tasks = 0, tr_lists = 0;
-    int4 desc = load_desc(t), desc_n = make_int4(0, 0, 0, 0);
-    int qid[QW], qid_n[QW];
-    load_qids(desc, qid);
-    bool has_next = t_n < ntasks;
-    if (has_next) desc_n = load_desc(t_n);
-    stage_load(desc.z, desc.w, kshift_of(desc.w), 0);
-
-    for (;;) {
-        asm volatile("" : "+s"(ap));   // opaque: argument loads below this point are not hoisted above the loop
-        const int row0 = __builtin_amdgcn_readfirstlane(desc.z), nrows = __builtin_amdgcn_readfirstlane(desc.w);
-        const int ntile = (nrows + 63) >> 6, kshift = kshift_of(nrows);
-        int nqw = (__builtin_amdgcn_readfirstlane(desc.y) - wave + NW - 1) / NW;
-        nqw = nqw < 0 ? 0 : (nqw > QW ? QW : nqw);
-        const int KBt = KB << kshift, RSt = KBt + 1, RPPt = RPP >> kshift;
-        const int nkb = (d4 + KBt - 1) / KBt;
-        const int sc = tid & (KBt - 1), sr = tid / KBt;
-        float acc[TPS][QW];
-#pragma unroll
-        for (int tl = 0; tl < TPS; ++tl)
-#pragma unroll
-            for (int jq = 0; jq < QW; ++jq) acc[tl][jq] = 0.0f;
-        const const_f32p qbase = (const_f32p)ap->qpad;
-        const int qstride = (int)ap->qpad_stride;   // Q * stride < 2^31 floats (Q < 2^31 / 1024 is checked by the host)
-
-        if (has_next && tid == 0) claim = atomicAdd(cursor, 1);   // id of the task after next; consumed at the end of this task
-        for (int kb = 0; kb < nkb; ++kb) {
-            [[maybe_unused]] const unsigned long long ta = SCAN_NOW();
-            __syncthreads();  // everyone has finished reading the previous k-block (or the previous task's last one)
-#pragma unroll
-            for (int i = 0; i < SPT; ++i) tile[(sr + RPPt * i) * RSt + sc] = stg[i];
-            __syncthreads();
-            [[maybe_unused]] const unsigned long long tb = SCAN_NOW();
-            tr_stage += tb - ta;
-            if (kb + 1 < nkb) {
-                stage_load(row0, nrows, kshift, kb + 1);  // in flight while this k-block is computed
-            } else if (has_next) {                         // last k-block: the NEXT task's first slice rides the idle staging registers
-                load_qids(desc_n, qid_n);
-                stage_load(desc_n.z, desc_n.w, kshift_of(desc_n.w), 0);
-            }
-            if (nqw > 0) {
-                const int nchunk = min(KBt, d4 - kb * KBt);
-                const_f32p qk[QW];
-#pragma unroll
-                for (int jq = 0; jq < QW; ++jq) qk[jq] = qbase + ((long long)__builtin_amdgcn_readfirstlane(qid[jq]) * qstride + kb * KBt * 4);
-                const float4 *col = tile + lane * RSt;
-
-                QChunk<QW> qa, qb;
-                load_qchunk<QW, false>(qa, qk, nqw, 0);
-                for (int c = 0; c < nchunk; c += 2) {
-                    const bool has1 = c + 1 < nchunk;
-                    load_qchunk<QW, false>(qb, qk, nqw, has1 ? c + 1 : c);
-#pragma unroll
-                    for (int tl = 0; tl < TPS; ++tl)
-                        if (tl < ntile) apply_qchunk<METRIC, QW, false>(qa, col[tl * 64 * RSt + c], nqw, acc[tl]);
-                    if (!has1) break;
-                    load_qchunk<QW, false>(qa, qk, nqw, c + 2 < nchunk ? c + 2 : c);
-#pragma unroll
-                    for (int tl = 0; tl < TPS; ++tl)
-                        if (tl < ntile) apply_qchunk<METRIC, QW, false>(qb, col[tl * 64 * RSt + c + 1], nqw, acc[tl]);
-                }
-            }
-#ifdef NLSH_SCAN_TRACE
-            {
-                float sink = 0.f;
-#pragma unroll
-                for (int tl = 0; tl < TPS; ++tl)
-#pragma unroll
-                    for (int jq = 0; jq < QW; ++jq) sink += acc[tl][jq];
-                asm volatile("" ::"v"(sink));
-                tr_comp += SCAN_NOW() - tb;
-            }
-#endif
-        }
-        [[maybe_unused]] const unsigned long long te0 = SCAN_NOW();
-        // epilogue of the current task (the next task's first slice and query ids are in flight meanwhile)
-        if (nqw > 0) {
-            asm volatile("" : "+s"(ap));
-            const int32_t *gidp = ap->gid;
-            const float *invp = ap->inv_norm;
-            unsigned long long *tauq = ap->tauq;
-            uint64_t *partial = ap->partial;
-            const int k = ap->k;
-            int32_t mygid[TPS];
-            float myinv[TPS];
-            bool valid[TPS];
-#pragma unroll
-            for (int tl = 0; tl < TPS; ++tl) {
-                valid[tl] = tl * 64 + lane < nrows;
-                const int prow = row0 + (valid[tl] ? tl * 64 + lane : 0);
-                mygid[tl] = valid[tl] ? gidp[prow] : -1;
-                myinv[tl] = (METRIC == NLSH_METRIC_COSINE && valid[tl]) ? invp[prow] : 0.0f;
-            }
-#pragma unroll
-            for (int jq = 0; jq < QW; ++jq) {
-                if (jq < nqw) {
-                    const uint64_t tau_g = global_tau_load(tauq + qid[jq]);
-                    uint64_t key[TPS];
-#pragma unroll
-                    for (int tl = 0; tl < TPS; ++tl) {
-                        const float dist = finish_distance<METRIC>(acc[tl][jq], myinv[tl]);
-                        const uint64_t kk = valid[tl] ? make_key(dist, mygid[tl]) : KEY_NONE;
-                        key[tl] = kk < tau_g ? kk : KEY_NONE;
-                    }
-                    uint64_t *out = partial + ((long long)t * (QW * NW) + wave + NW * jq) * k;
-                    const uint64_t bound = select_k_smallest<TPS>(key, k, lane, out);
-                    if (bound != KEY_NONE && lane == 0) atomicMin(tauq + qid[jq], (unsigned long long)bound);
-                }
-            }
-        }
-#ifdef NLSH_SCAN_TRACE
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        tr_epi += SCAN_NOW() - te0;
-        tr_tasks += 1;
-        tr_lists += nqw;
-#endif
-        [[maybe_unused]] const unsigned long long ts0 = SCAN_NOW();
-        if (!has_next) break;
-        // hand the claimed id to the other waves: written before, read after the barriers of the next task's first k-block
-        // (all waves have read the previous value long ago: it was consumed right after THIS task's first barrier pair)
-        if (tid == 0) next_id[0] = task_of(claim);
-        t = t_n;
-        desc = desc_n;
-#pragma unroll
-        for (int jq = 0; jq < QW; ++jq) qid[jq] = qid_n[jq];
-        __syncthreads();
-        t_n = __builtin_amdgcn_readfirstlane(next_id[0]);
-        has_next = t_n < ntasks;
-        if (has_next) desc_n = load_desc(t_n);
-        tr_sw += SCAN_NOW() - ts0;
-    }
-#ifdef NLSH_SCAN_TRACE
-    if (lane == 0 && blockIdx.x * 4 + wave < NLSH_TRACE_SLOTS) {
-        float *o = g_scan_trace + (blockIdx.x * 4 + wave) * 8;
-        o[0] = (float)(SCAN_NOW() - tr0); o[1] = (float)tr_stage; o[2] = (float)tr_comp; o[3] = (float)tr_epi;
-        o[4] = (float)tr_sw; o[5] = (float)tr_tasks; o[6] = (float)tr_lists; o[7] = (float)(tr0 & 0xFFFFFFull);
-    }
-#endif
+    tiled_task_body<METRIC, QW, NW, TPS>(a, tile, t, desc, qid_v, tid, lane, wave, ts_entry);
 }
 
 __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
@@ -1059,40 +914,8 @@ constexpr int TILED_QB = NLSH_TILED_QB;  // queries per task of the tiled schedu
 #endif
 constexpr int TILED_TPS = NLSH_TILED_TPS;  // 64-row tiles per task of the tiled schedule (segment = 64*TPS rows)
 
-// NLSH_TILED_VARIANT (environment, diagnostic A/B only): 0 = one-shot workgroups (default), 1 = persistent
-static int tiled_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("NLSH_TILED_VARIANT");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
-}
-
-// resident workgroups of the persistent kernel on the current device: CUs x occupancy, a multiple of 128
-static unsigned persistent_grid(int metric) {
-    static unsigned g[2] = {0, 0};
-    unsigned &r = g[metric == NLSH_METRIC_L2_EPS ? 0 : 1];
-    if (r == 0) {
-        int dev = 0, cus = 256, occ = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (metric == NLSH_METRIC_L2_EPS)
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, bscan3p_kernel<NLSH_METRIC_L2_EPS, 4, TILED_QB / 4, TILED_TPS>, 64 * (TILED_QB / 4), 0);
-        else
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, bscan3p_kernel<NLSH_METRIC_COSINE, 4, TILED_QB / 4, TILED_TPS>, 64 * (TILED_QB / 4), 0);
-        if (occ < 1) occ = 4;
-        const char *e = getenv("NLSH_TILED_OCC");   // diagnostic: cap the resident workgroups per CU
-        if (e && atoi(e) > 0 && atoi(e) < occ) occ = atoi(e);
-        unsigned n = (unsigned)cus * (unsigned)occ;
-        n = n / 128 * 128;
-        r = n < 128 ? 128 : n;
-    }
-    return r;
-}
-
 struct BWs {
-    size_t pbkt, prec, inv_q, bcount, pairoff, taskoff, bgroups, counters, btot, task, partial, qpad, tauq, total;
+    size_t pbkt, prec, inv_q, bcount, pairoff, taskoff, bgroups, counters, btot, task, task_q, partial, qpad, tauq, total;
 };
 static void blayout(long long Q, int P, int k, long long max_tasks, long long nb, int d, bool tiled, BWs *w) {
     size_t o = 0;
@@ -1107,6 +930,7 @@ static void blayout(long long Q, int P, int k, long long max_tasks, long long nb
     w->counters = o; o += ws_align(64);
     w->btot = o;     o += ws_align((size_t)((nb + 255) / 256 + 1) * 8);
     w->task = o;     o += ws_align((size_t)max_tasks * sizeof(int4));
+    w->task_q = o;   o += tiled ? ws_align((size_t)max_tasks * TILED_QB * 4) : 0;
     w->partial = o;  o += ws_align((size_t)max_tasks * (tiled ? TILED_QB : 8) * k * 8);
     w->qpad = o;     o += tiled ? ws_align((size_t)Q * ((d + 3) / 4) * 16) : 0;
     w->tauq = o;     o += ws_align((size_t)Q * 8);
@@ -1146,7 +970,7 @@ int bucket_scan_run(const BucketScanCall &c) {
     char *base = (char *)c.workspace;
     a.pbkt = (int32_t *)(base + w.pbkt); a.prec = (int4 *)(base + w.prec); a.inv_q = (int32_t *)(base + w.inv_q);
     a.bcount = (int32_t *)(base + w.bcount); a.pairoff = (int32_t *)(base + w.pairoff); a.taskoff = (int32_t *)(base + w.taskoff); a.bgroups = (int32_t *)(base + w.bgroups);
-    a.counters = (int32_t *)(base + w.counters); a.btot = (int32_t *)(base + w.btot); a.border = c.bucket_order; a.task = (int4 *)(base + w.task); a.partial = (uint64_t *)(base + w.partial);
+    a.counters = (int32_t *)(base + w.counters); a.btot = (int32_t *)(base + w.btot); a.border = c.bucket_order; a.task = (int4 *)(base + w.task); a.task_q = c.tiled ? (int32_t *)(base + w.task_q) : nullptr; a.partial = (uint64_t *)(base + w.partial);
     a.max_tasks = c.max_tasks;
     a.tauq = (unsigned long long *)(base + w.tauq);
 
@@ -1171,17 +995,11 @@ int bucket_scan_run(const BucketScanCall &c) {
         if (c.ev_begin) NLSH_CHECK_HIP(hipEventRecord((hipEvent_t)c.ev_begin, s));
         if (c.tiled) {
             // QW = 4 queries per wave (SGPR budget: two chunks x QW x 4 scalar values in flight), NW = 4 waves
-            if (tiled_variant() == 0) {   // one-shot workgroups (r01): one per task, the chunked XCD map works on 8 x 16 ids
-                const unsigned grid = (unsigned)((c.max_tasks + 127) / 128 * 128);
-                if (c.metric == NLSH_METRIC_L2_EPS) hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_L2_EPS, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
-                else hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_COSINE, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
-            } else {                       // persistent workgroups: CUs x occupancy, rounded to the XCD map's 128
-                const unsigned resident = persistent_grid(c.metric);
-                const unsigned need = (unsigned)((c.max_tasks + 127) / 128 * 128);
-                const unsigned grid = need < resident ? need : resident;
-                if (c.metric == NLSH_METRIC_L2_EPS) hipLaunchKernelGGL((bscan3p_kernel<NLSH_METRIC_L2_EPS, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
-                else hipLaunchKernelGGL((bscan3p_kernel<NLSH_METRIC_COSINE, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
-            }
+            // one workgroup per task; the chunked XCD map works on 8 x 16 ids.  (Persistent workgroups pulling tasks from a
+            // per-XCD queue were measured three ways in r02 -- 0.447 / 0.423 / 0.350 ms against 0.283 ms: DESIGN.md 4.2.)
+            const unsigned grid = (unsigned)((c.max_tasks + 127) / 128 * 128);
+            if (c.metric == NLSH_METRIC_L2_EPS) hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_L2_EPS, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
+            else hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_COSINE, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
         } else {
             const unsigned grid = (unsigned)((c.max_tasks + 3) / 4);  // one wavefront per task
             if (c.metric == NLSH_METRIC_L2_EPS) launch_bscan2<NLSH_METRIC_L2_EPS>(a, d4, grid, s);

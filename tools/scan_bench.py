@@ -4,7 +4,7 @@ then times the scan phase alone (HIP events around the scan kernel, as bench.py 
 step, and checks the result against the query-major schedule (ids equal up to fp32 near-ties, candidate counts exact).
 
     python tools/scan_bench.py [--algo tiled] [--iters 30] [--workload sift1m|glove]
-    NLSH_TILED_VARIANT=0 python tools/scan_bench.py      # r01 one-shot workgroups, for A/B
+    NLSH_HIP_LIB=/path/to/other/build.so python tools/scan_bench.py --tag other      # A/B against another build
 """
 import argparse
 import json
@@ -67,7 +67,7 @@ def main():
     torch.cuda.synchronize()
     step_ms = 1e3 * (time.perf_counter() - t0) / args.iters
     dist, idx, nc, _ = out
-    rec = {"tag": args.tag, "variant": os.environ.get("NLSH_TILED_VARIANT", "default"), "algo": args.algo,
+    rec = {"tag": args.tag, "lib": os.path.basename(os.environ.get("NLSH_HIP_LIB", "default")), "algo": args.algo,
            "scan_kernel_ms": float(kern.mean()), "scan_kernel_ms_min": float(kern.min()), "scan_phases_ms": scan_call_ms,
            "step_ms": step_ms, "tasks": int(ix.last_status.cpu()[0]), "sum_candidates": int(nc.long().sum())}
     if not args.no_check:

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Phase timeline of the tiled scan's workgroups (diagnostic).  Needs the library built with
-`make -C neural-locality-sensitive-hashing_amd/csrc EXTRA=-DNLSH_SCAN_TRACE`.  Runs the headline workload once
-and prints, over all tasks, the mean / total wall-clock (100 MHz ticks) wave 0 spent per phase."""
+"""Phase breakdown of the tiled scan's workgroups (diagnostic).  Needs the library built with -DNLSH_SCAN_TRACE
+(NLSH_HIP_LIB=path/to/that/build).  Runs the headline workload and prints, per task shape, where wave 0 of a
+workgroup spends its time (100 MHz wall-clock ticks -> us): prologue (launch -> first stage issued), barrier-1 wait
+(the slowest wave's previous k-block), stage (own loads + LDS write + barrier 2), compute, epilogue (selection)."""
 import ctypes
 import os
 import sys
@@ -21,7 +22,7 @@ corpus_h, mean, std = synth.standardise(synth.sift_manifold(N, d, seed=synth.SEE
 queries_h, _, _ = synth.standardise(synth.sift_manifold(Q, d, seed=synth.SEED_QUERY), mean, std)
 Ws, bs = io.load_hasher_weights(os.path.join(ROOT, "neural-locality-sensitive-hashing_amd", "checkpoints", "sift1m_manifold_h16.npz"))
 hashing = io.hashing_from_weights(Ws, bs, compat=True)
-indexer = Indexer(hashing, torch.from_numpy(corpus_h).cuda(), SIFT.distance)
+indexer = Indexer(hashing, torch.from_numpy(corpus_h).cuda(), SIFT.distance, algo="tiled")
 queries = torch.from_numpy(queries_h).cuda()
 for i in range(3):
     indexer.query_tensors(queries, k=10, hash_times=10, seed=7)
@@ -31,39 +32,35 @@ L = _capi.lib()
 buf = np.zeros((min(n_tasks, 1 << 16), 8), dtype=np.float32)
 rc = L.nlsh_debug_scan_trace(buf.ctypes.data_as(ctypes.c_void_p), int(buf.size))
 assert rc == 0, rc
-names = ["total", "prologue", "stage(barriers+lds write)", "compute", "start stamp (24 bit)", "select", "nq", "nrows"]
-print(f"tasks {n_tasks}")
-for i, nm in enumerate(names):
-    print(f"  {nm:28s} mean {buf[:, i].mean():9.1f}   sum {buf[:, i].sum():12.0f}")
-full = buf[(buf[:, 6] == 16) & (buf[:, 7] == 256)]
-print(f"full tasks (16 queries x 256 rows): {len(full)}")
-for i, nm in enumerate(names[:6]):
-    print(f"  {nm:28s} mean {full[:, i].mean():9.1f}")
-
-# concurrency over time: workgroups in flight per 10 us bucket (start stamps are device-wide 100 MHz ticks)
-start = buf[:, 4].astype(np.int64)
+np.save(os.path.join(ROOT, 'gpurun_out', 'scan_trace.npy'), buf)
+buf = buf[buf[:, 0] > 0]
+start = buf[:, 7].astype(np.int64)
+nq_nrows = buf[:, 6].astype(np.int64)
+buf[:, 6], buf[:, 7] = nq_nrows // 1000, nq_nrows % 1000
+tot = buf[:, 0].sum()
+print(f"tasks {n_tasks} traced {len(buf)}; summed workgroup time {tot / 100:.0f} us = {tot / 100 / 1792:.1f} us x 1792 slots")
+print(f"{'queries':>8s} {'rows':>8s} {'tasks':>6s} {'time%':>6s} {'mean us':>8s} | {'prolog':>7s} {'bar1':>7s} {'stage':>7s} {'compute':>7s} {'select':>7s} {'other':>7s}")
+for qlo, qhi in ((1, 1), (2, 4), (5, 8), (9, 12), (13, 15), (16, 16)):
+    for rlo, rhi in ((1, 64), (65, 128), (129, 255), (256, 256)):
+        m = (buf[:, 6] >= qlo) & (buf[:, 6] <= qhi) & (buf[:, 7] >= rlo) & (buf[:, 7] <= rhi)
+        if not m.any():
+            continue
+        b = buf[m]
+        mean = b[:, 0].mean()
+        parts = [b[:, 1].mean(), b[:, 2].mean(), b[:, 4].mean(), b[:, 3].mean(), b[:, 5].mean()]
+        other = mean - sum(parts)
+        print(f"{qlo:3d}-{qhi:<4d} {rlo:3d}-{rhi:<4d} {m.sum():6d} {100 * b[:, 0].sum() / tot:6.1f} {mean / 100:8.1f} | " +
+              " ".join(f"{v / 100:7.1f}" for v in parts + [other]))
+b = buf
+parts = [b[:, 1].sum(), b[:, 2].sum(), b[:, 4].sum(), b[:, 3].sum(), b[:, 5].sum()]
+print("all tasks, share of summed time: prologue %.3f  barrier-1 %.3f  stage %.3f  compute %.3f  select %.3f  other %.3f" %
+      tuple([v / tot for v in parts] + [1 - sum(parts) / tot]))
+# concurrency over time: workgroups in flight per 10 us slice (start stamps are device-wide 100 MHz ticks, 24 bits kept)
 start = (start - start.min()) % (1 << 24)
 end = start + buf[:, 0].astype(np.int64)
 span = int(end.max())
-edges = np.arange(0, span + 1000, 1000)
-busy = np.zeros(len(edges) - 1)
+busy = np.zeros(span // 1000 + 1)
 for s0, e0 in zip(start, end):
-    a, b = s0 // 1000, min(e0 // 1000, len(busy) - 1)
-    busy[a:b + 1] += 1
-print(f"kernel span {span / 100:.1f} us; workgroups in flight per 10 us slice (1024 = 4 per CU):")
-print(" ".join(f"{int(v)}" for v in busy))
-order = np.argsort(start)
-print("first/last task start (us):", start[order[0]] / 100, start[order[-1]] / 100, " last end:", end.max() / 100)
-# who uses the workgroup time: share of the summed task time by task shape
-tot = buf[:, 0].sum()
-print("share of summed workgroup time / of tasks, by (queries, rows) of the task:")
-for qlo, qhi in ((1, 1), (2, 4), (5, 8), (9, 15), (16, 16)):
-    for rlo, rhi in ((1, 64), (65, 128), (129, 255), (256, 256)):
-        m = (buf[:, 6] >= qlo) & (buf[:, 6] <= qhi) & (buf[:, 7] >= rlo) & (buf[:, 7] <= rhi)
-        if m.any():
-            print(f"  nq {qlo:2d}-{qhi:2d} rows {rlo:3d}-{rhi:3d}: time {buf[m, 0].sum() / tot:6.3f}  tasks {m.mean():6.3f}  mean {buf[m, 0].mean() / 100:6.1f} us")
-small = buf[(buf[:, 6] <= 4) & (buf[:, 7] <= 64)]
-print(f"small tasks (<= 4 queries x <= 64 rows): {len(small)}")
-for i, nm in enumerate(names[:6]):
-    if i != 4:
-        print(f"  {nm:28s} mean {small[:, i].mean():9.1f}")
+    busy[s0 // 1000:e0 // 1000 + 1] += 1
+print(f"kernel span {span / 100:.1f} us (first entry -> last exit); workgroups in flight per 10 us slice (1792 = 7 per CU):")
+print(" ".join(str(int(v)) for v in busy))
