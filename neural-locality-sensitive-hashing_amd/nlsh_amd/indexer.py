@@ -12,7 +12,6 @@ reference quirks: int16 key wrap (F2), single-probe trailing partial batch (F6),
 last key's bucket rows (F7).  No CPU fallback exists anywhere in this module.
 """
 import gc
-import os
 from typing import Dict, List, Optional, Sequence, Set, Tuple
 
 import numpy as np
@@ -147,32 +146,9 @@ class Indexer:
             ows = torch.empty((ob,), dtype=torch.uint8, device=dev)
             _capi.check(L.nlsh_bucket_order(_capi.ptr(self.offsets), self.n_buckets, _capi.ptr(self.bucket_order), _capi.ptr(ows),
                                             ob, _stream(dev)))
-            self.bucket_order = self._riffle_schedule(self.bucket_order[:self.n_buckets])
         self._uniq_host = self.uniq_keys.cpu().numpy()
         self._offs_host = self.offsets.cpu().numpy().astype(np.int64)
         self.bucket_sizes = np.diff(self._offs_host)
-
-    def _riffle_schedule(self, by_size_desc):
-        """Schedule order of the buckets for the bucket-major scans, from the size-descending order the library returns.
-
-        Largest-first alone runs the batch in two phases: the big buckets' tasks (256 rows x 16 queries: VALU-bound) first,
-        then thousands of tiny tasks (<= 64 rows, a query or two) that are pure latency -- a dependent load chain and two
-        stages each with next to no arithmetic -- during which the vector units idle (r02 ablation: the staging skeleton
-        alone takes 0.12 ms of a 0.28 ms launch and adds to the arithmetic instead of hiding under it).  The tiny buckets
-        are therefore paced through the WHOLE launch: bucket i (size order) is scheduled at min(share of the total cost
-        before it, share of the buckets after it), cost ~ size^2 (a bucket is probed about in proportion to its size), so
-        the front of the list is consumed by cost and the back by count, and every window of the task list holds the same
-        mix of heavy and light work.  Static per index; results do not depend on it (placement only changes speed)."""
-        nb = int(by_size_desc.shape[0])
-        if nb < 64 or os.environ.get("NLSH_BUCKET_ORDER", "riffle") == "size":
-            return by_size_desc
-        order = by_size_desc.long()
-        sz = (self.offsets[1:] - self.offsets[:-1])[order].double()
-        cost = sz * sz
-        t_front = (torch.cumsum(cost, 0) - cost) / cost.sum().clamp_min(1.0)
-        t_back = (nb - 1 - torch.arange(nb, device=order.device, dtype=torch.float64)) / nb
-        when = torch.minimum(t_front, t_back)
-        return by_size_desc[torch.argsort(when, stable=True)].contiguous()
 
     @property
     def index2row(self) -> Dict[int, torch.Tensor]:
