@@ -211,9 +211,11 @@ def main():
         return float(t.item())
 
     # ------------------------------------------------------------------ region A: the reference's protocol (headline)
+    own = True
+
     def query_lists(i):
-        if sharded is not None:
-            return sharded.query(qb[i % B], k=k, hash_times=P, seed=5000 + i)     # same seed on every rank
+        if sharded is not None:   # same seed on every rank; rank r builds the lists of its Q/N slice of the batch
+            return sharded.query(qb[i % B], k=k, hash_times=P, seed=5000 + i, own_slice=own)
         return indexer.query(qb[i % B], k=k, hash_times=P)
 
     for i in range(max(warmup, 1)):        # at least one: sizes the task table (may retry once); untimed
@@ -227,7 +229,8 @@ def main():
         call_s.append(time.perf_counter() - t1)
     fence()
     elapsed = max_over_ranks(time.perf_counter() - t0)
-    assert isinstance(ids_api, list) and len(ids_api) == Q and isinstance(nc_api, list)
+    q_lo, q_hi = shard_range(Q, rank, world)
+    assert isinstance(ids_api, list) and len(ids_api) == q_hi - q_lo and isinstance(nc_api, list)
 
     # ------------------------------------------------------------------ region B: same path, results left in HBM
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
@@ -338,6 +341,7 @@ def main():
         corpus_d = torch.from_numpy(corpus_h).to(dev)
         gt = brute_force_topk(qb[0], corpus_d, k, metric).cpu().numpy()
         del corpus_d
+    own = False                      # untimed: all lists on every rank (rank 0 computes the recall from them)
     ids0, nc0 = query_lists(0)       # every rank takes part in the (collective) protocol call the recall is computed from
     if rank == 0:
         recall = float(np.mean(calculate_recall(list(gt), ids0)))
@@ -371,7 +375,8 @@ def main():
             "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "recall_at_10": recall,
-            "value_protocol": "Indexer.query(batch, k, hash_times) -> Python lists, K synchronous calls (nlsh/trainers/base.py:93-96)",
+            "value_protocol": "Indexer.query(batch, k, hash_times) -> Python lists, K synchronous calls (nlsh/trainers/base.py:93-96)" +
+                              ("" if world == 1 else f"; sharded: every rank scans all queries over its shard and returns the lists of its 1/{world} slice of the batch"),
             "protocol_median_qps": Q / float(np.median(call_s)),
             "device_resident_qps": Q * steps / elapsed_dev, "device_resident_ms_per_step": 1e3 * elapsed_dev / steps,
             "config": {"workload": f"{wl['cfg']}, N={N} d={d} Q={Q} H={H} k={k} hash_times={P}, {B} query batches in rotation",

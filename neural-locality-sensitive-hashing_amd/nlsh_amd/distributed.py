@@ -262,11 +262,16 @@ class ShardedIndexer:
             return merge_topk_device(torch.cat([keys64, ncand.long()[:, None]], dim=1)[None], k)
         return gather_and_merge(keys64, ncand, k, self.group)
 
-    def query(self, query_vectors, k=10, hash_times=10, seed=None):
+    def query(self, query_vectors, k=10, hash_times=10, seed=None, own_slice=False):
         """`Indexer.query` (nlsh/indexer.py:56-96) over the sharded corpus: the reference's `(List[List[int]],
-        List[int])` on EVERY rank, identical to the single-GPU answer.  hash -> local scan -> all-gather + merge -> one
+        List[int])`, identical to the single-GPU answer.  hash -> local scan -> all-gather + merge -> one
         device->host copy.  The multi-probe seed comes from the hasher's call counter (identical on all ranks as long
-        as they make the same calls) unless given."""
+        as they make the same calls) unless given.
+
+        own_slice=False: every rank returns the lists of ALL queries.  own_slice=True: rank r returns the lists of ITS
+        contiguous slice `shard_range(Q, r, G)` of the batch only -- every rank still scans all queries over its shard
+        (the merged device tensors are complete everywhere), but the host-side work of the reference's return type
+        (device->host copy + 10^5 Python ints per 10^4 queries) is divided over the ranks like the scan is."""
         import numpy as np
         local = self.local
         if seed is None:
@@ -274,30 +279,36 @@ class ShardedIndexer:
         keys, nkeys = local.hash_device(query_vectors, hash_times=hash_times, seed=seed)
         _, _, ncand, keys64 = local.scan_tensors(query_vectors, keys, nkeys, k=k, want_keys=True)
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        rank = dist.get_rank(self.group) if world > 1 else 0
         if world == 1:
             _, idx, nc = merge_topk_device(torch.cat([keys64, ncand.long()[:, None]], dim=1)[None], k)
         else:
             _, idx, nc = gather_and_merge(keys64, ncand, k, self.group)
-        idx_h, nc_h = idx.cpu().numpy(), nc.cpu().numpy()
-        short = np.nonzero(nc_h < k)[0]
-        key_sets = {}
-        if local.compat and short.size:
-            from .hashings import keys_to_sets
-            sel = torch.as_tensor(short, device=keys.device)
-            key_sets = dict(zip(short.tolist(), keys_to_sets(keys[sel], nkeys[sel], local._hashing.key_mode)))
+        Q = idx.shape[0]
+        lo, hi = shard_range(Q, rank, world) if own_slice else (0, Q)
+        idx_h, nc_h = idx[lo:hi].cpu().numpy(), nc[lo:hi].cpu().numpy()
         results, counts = local._plain_lists(idx_h, nc_h)                        # short lists are replaced below
-        if short.size:
+        # queries with fewer than k candidates (rare): which ones is known from the MERGED counts, identical on every rank,
+        # so the pooled F7 lookup below is entered by all ranks or by none, whoever owns the slice
+        nc_all = nc_h if not own_slice else nc.cpu().numpy()
+        short_all = np.nonzero(nc_all < k)[0]
+        if short_all.size:
             if local.compat:
+                from .hashings import keys_to_sets
+                sel = torch.as_tensor(short_all, device=keys.device)
+                sets = keys_to_sets(keys[sel], nkeys[sel], local._hashing.key_mode)
                 # F7 (indexer.py:91-93): rows of the LAST key of the set; the bucket lives on one rank (bucket partition)
-                # or is split over all (row partition), so the ranks pool their parts (rare path: C_q < k)
-                mine = [local._rows_of_key(list(key_sets[qi])[-1]) if key_sets[qi] else [] for qi in short.tolist()]
+                # or is split over all (row partition), so the ranks pool their parts
+                mine = [local._rows_of_key(list(s_)[-1]) if s_ else [] for s_ in sets]
                 if world > 1:
                     pooled = [None] * world
                     dist.all_gather_object(pooled, mine, group=self.group)
                     mine = [sorted(sum((p[i] for p in pooled), [])) for i in range(len(mine))]
-                for qi, rows in zip(short.tolist(), mine):
-                    results[qi] = rows
+                for qi, rows in zip(short_all.tolist(), mine):
+                    if lo <= qi < hi:
+                        results[qi - lo] = rows
             else:
-                for qi in short.tolist():
-                    results[qi] = [int(v) for v in idx_h[qi] if v >= 0]
+                for qi in short_all.tolist():
+                    if lo <= qi < hi:
+                        results[qi - lo] = [int(v) for v in idx_h[qi - lo] if v >= 0]
         return results, counts

@@ -195,6 +195,14 @@ class MultivariateBernoulli:
         return keys, nkeys, probs
 
 
+def host_key_set(row, count, key_mode=_capi.KEY_REF_INT16) -> Set[int]:
+    """One row of a HOST key table -> the reference's key set (same construction as `keys_to_sets`, so the same
+    Python iteration order: the F7 fallback names the LAST key of that order)."""
+    if key_mode == _capi.KEY_FULL:
+        row = row.astype("int64") & 0xFFFFFFFF
+    return set(row[:count].tolist())
+
+
 def keys_to_sets(keys, nkeys, key_mode=_capi.KEY_REF_INT16) -> List[Set[int]]:
     """Device key table -> the reference's `List[Set[int]]` (one D2H copy, then host objects)."""
     kh = keys.cpu().numpy()

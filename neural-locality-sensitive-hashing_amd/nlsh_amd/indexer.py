@@ -19,7 +19,7 @@ import torch
 
 from . import _capi
 from .data import metric_of
-from .hashings import keys_to_sets
+from .hashings import host_key_set, keys_to_sets
 
 HASH_BATCH = 4096  # nlsh/indexer.py:40 default batch_size
 
@@ -335,22 +335,27 @@ class Indexer:
         return self._perm_host[lo:hi].tolist()
 
     def _host_results(self, q, keys, nkeys, k):
-        """Scan + ONE device->host copy of (ids, candidate counts, status) into a pinned buffer + one stream
-        synchronisation: the only sync of a `query()` call.  Repeats the scan if the task table overflowed."""
+        """Scan + device->host copies of (ids, candidate counts, status) and of the key table into pinned buffers + ONE
+        stream synchronisation: the only sync of a `query()` call (the key table rides along because the F7 rule needs
+        the key sets of the few queries with < k candidates: 400 KB more on the wire is cheaper than a second round of
+        device indexing + copies + syncs after the first).  Repeats the scan if the task table overflowed."""
+        Q, P = keys.shape
         while True:
             _, idx, ncand, _ = self.scan_tensors(q, keys, nkeys, k=k, check=False)
             pack, tkey = self._last_pack, self._last_tkey
-            n = pack.numel()
+            n, nk = pack.numel(), Q * P + Q
             pin = self._pin
-            if pin is None or pin.numel() < n:
-                pin = self._pin = torch.empty((max(n, 1 << 16),), dtype=torch.int32, pin_memory=True)
+            if pin is None or pin.numel() < n + nk:
+                pin = self._pin = torch.empty((max(n + nk, 1 << 16),), dtype=torch.int32, pin_memory=True)
             pin[:n].copy_(pack, non_blocking=True)
+            if self.compat:
+                pin[n:n + Q * P].view(Q, P).copy_(keys, non_blocking=True)
+                pin[n + Q * P:n + nk].copy_(nkeys, non_blocking=True)
             torch.cuda.current_stream(q.device).synchronize()
-            host = pin[:n].numpy()
-            Q = q.shape[0]
+            host = pin.numpy()
             needed, overflow = int(host[n - 2]), int(host[n - 1])
             if not overflow or Q == 0:
-                return host[:Q * k].reshape(Q, k), host[Q * k:Q * k + Q]
+                return (host[:Q * k].reshape(Q, k), host[Q * k:Q * k + Q], host[n:n + Q * P].reshape(Q, P), host[n + Q * P:n + nk])
             self._max_tasks[tkey] = int(needed * 1.25) + 1024
 
     @staticmethod
@@ -384,15 +389,13 @@ class Indexer:
         if keys.shape[1] > _capi.MAX_PROBES:
             _, idx, ncand, _ = self.scan_tensors(q, keys, nkeys, k=k)
             idx_h, nc_h = idx.cpu().numpy(), ncand.cpu().numpy()
+            keys_h, nkeys_h = (keys.cpu().numpy(), nkeys.cpu().numpy()) if self.compat else (None, None)
         else:
-            idx_h, nc_h = self._host_results(q, keys, nkeys, k)
+            idx_h, nc_h, keys_h, nkeys_h = self._host_results(q, keys, nkeys, k)
         key_sets = {}
         if self.compat:  # F7 needs the key SET (Python iteration order) of the queries with < k candidates only
-            short = np.nonzero(nc_h < k)[0]
-            if short.size:
-                sel = torch.as_tensor(short, device=keys.device)
-                sets = keys_to_sets(keys[sel], nkeys[sel], self._hashing.key_mode)
-                key_sets = dict(zip(short.tolist(), sets))
+            for qi in np.nonzero(nc_h < k)[0].tolist():
+                key_sets[qi] = host_key_set(keys_h[qi], int(nkeys_h[qi]), self._hashing.key_mode)
         return self._to_lists(key_sets, idx_h, nc_h, k)
 
     def _as_queries(self, query_vectors):

@@ -58,6 +58,13 @@ def _worker(rank, world, port, shard, out_dir):
         out = pipe.submit(b, seed=70 + i)
         pipe.synchronize()                                               # exchange outputs are fresh tensors: read at once
         piped.append(tuple(t.cpu().numpy() for t in out[:3]))
+    # reference-typed call: all lists on every rank, or each rank the lists of its slice of the batch
+    lists_all, nc_all = sharded.query(qd[0], k=k, hash_times=P, seed=70)
+    lists_own, nc_own = sharded.query(qd[0], k=k, hash_times=P, seed=70, own_slice=True)
+    qlo, qhi = shard_range(len(batches[0]), rank, world)
+    assert lists_own == lists_all[qlo:qhi] and nc_own == nc_all[qlo:qhi]
+    import json
+    json.dump({"ids": lists_all, "nc": nc_all}, open(os.path.join(out_dir, f"lists{rank}.json"), "w"))
     if rank == 0:
         np.savez(os.path.join(out_dir, "merged.npz"), **{f"{tag}{i}_{j}": a for tag, res in (("d", direct), ("p", piped))
                                                          for i, r in enumerate(res) for j, a in enumerate(r)},
@@ -83,6 +90,15 @@ def test_two_rank_sharded_pipeline_equals_single_index(tmp_path, shard):
             assert np.array_equal(got[f"{tag}{i}_0"], dist_.cpu().numpy()), (tag, i)
             assert np.array_equal(got[f"{tag}{i}_2"], nc_.cpu().numpy()), (tag, i)
     assert 0.4 * len(corpus) < int(got["rows"][0]) < 0.6 * len(corpus)
+    # the reference-typed lists: identical on both ranks and equal to the single index's answer for the same keys
+    import json
+    l0, l1 = (json.load(open(tmp_path / f"lists{r}.json")) for r in range(2))
+    assert l0 == l1
+    qd0 = torch.from_numpy(batches[0]).to(dev)
+    keys, nkeys = single.hash_device(qd0, hash_times=6, seed=70)
+    want, want_nc, _, _ = single.query_with_keys(qd0, single.hash(qd0, hash_times=6) and
+                                                 [list(s_) for s_ in __import__("nlsh_amd.hashings", fromlist=["keys_to_sets"]).keys_to_sets(keys, nkeys)], k=10)
+    assert l0["nc"] == want_nc and l0["ids"] == want
 
 
 def test_bench_gpus_2_self_launch_reports_two_ranks():
