@@ -185,7 +185,10 @@ __global__ __launch_bounds__(NW * 64) void encode_hash_kernel(EncArgs a) {
                     for (int i = 0; i < 16; ++i) acc[rt][i] = 0.0f;
                 const float4 *w0 = Wp + (size_t)nt0 * nch * 64 + lane;
                 const float *arow = in + (size_t)lr * S + 4 * lh;
-                // B fragments ride a ring of four registers, fetched THREE k-chunks (24 MFMAs) ahead of their use.
+                // B fragments ride a ring of four registers, fetched THREE k-chunks (24 MFMAs) ahead of their use
+                // (r02: a ring of eight / seven chunks ahead measured 2.25 ms per 1M rows and 49.7 us per 10k queries against
+                // 2.2 ms / 44 us -- the ring is not what the MFMA pipe waits for; a 64-row SINGLE image for index builds needs
+                // 172 VGPRs, so two workgroups per CU only fit with 42 spilled registers: 2.41 ms).
                 // The ring is indexed statically (main loop unrolled by 4, branch-free: indices past the end are
                 // clamped and their data unused), so neither a register rotation nor a control-flow join makes
                 // the compiler wait for the youngest load; A fragments (LDS) are fetched one chunk ahead.
