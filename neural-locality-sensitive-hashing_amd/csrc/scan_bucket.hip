@@ -528,41 +528,81 @@ __device__ __forceinline__ void load_qset(QSet &q, const const_f32p (&qk)[4], in
         asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(q.v[0]) : "s"(qk[0]), "s"(byte_off), "v"(after));
 }
 
+// One (tile, chunk) block = NQ query blocks in ONE asm statement: the compiler pads every inline-asm statement with an
+// s_nop (it cannot see the hazards inside), and per-query statements left 25 of them per chunk pair in the hot loop.
+#define NLSH_QBLK(J)                                                                                               \
+    "v_sub_f32 %[t0], %[q" #J "0], %[r0]\n\tv_sub_f32 %[t1], %[q" #J "1], %[r1]\n\t"                                 \
+    "v_sub_f32 %[t2], %[q" #J "2], %[r2]\n\tv_sub_f32 %[t3], %[q" #J "3], %[r3]\n\t"                                 \
+    "v_add_f32 %[t0], 0x358637bd, %[t0]\n\tv_add_f32 %[t1], 0x358637bd, %[t1]\n\t"                                   \
+    "v_add_f32 %[t2], 0x358637bd, %[t2]\n\tv_add_f32 %[t3], 0x358637bd, %[t3]\n\t"                                   \
+    "v_fmac_f32 %[a" #J "], %[t0], %[t0]\n\tv_fmac_f32 %[a" #J "], %[t1], %[t1]\n\t"                                 \
+    "v_fmac_f32 %[a" #J "], %[t2], %[t2]\n\tv_fmac_f32 %[a" #J "], %[t3], %[t3]\n\t"
+#define NLSH_QIN(J) [q##J##0] "s"(q.v[J].x), [q##J##1] "s"(q.v[J].y), [q##J##2] "s"(q.v[J].z), [q##J##3] "s"(q.v[J].w)
+#define NLSH_TMP [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+#define NLSH_RIN [r0] "v"(r.x), [r1] "v"(r.y), [r2] "v"(r.z), [r3] "v"(r.w)
 template <int NQ>
 __device__ __forceinline__ void l2_tile_block(float (&acc)[4], const float4 r, const QSet &q) {
-#pragma unroll
-    for (int jq = 0; jq < NQ; ++jq) l2_query_block(acc[jq], r, q.v[jq]);
+    float t0, t1, t2, t3;
+    if (NQ == 4)
+        asm volatile(NLSH_QBLK(0) NLSH_QBLK(1) NLSH_QBLK(2) NLSH_QBLK(3)
+                     : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), NLSH_TMP
+                     : NLSH_RIN, NLSH_QIN(0), NLSH_QIN(1), NLSH_QIN(2), NLSH_QIN(3));
+    else if (NQ == 3)
+        asm volatile(NLSH_QBLK(0) NLSH_QBLK(1) NLSH_QBLK(2)
+                     : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), NLSH_TMP
+                     : NLSH_RIN, NLSH_QIN(0), NLSH_QIN(1), NLSH_QIN(2));
+    else if (NQ == 2)
+        asm volatile(NLSH_QBLK(0) NLSH_QBLK(1) : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), NLSH_TMP : NLSH_RIN, NLSH_QIN(0), NLSH_QIN(1));
+    else
+        asm volatile(NLSH_QBLK(0) : [a0] "+v"(acc[0]), NLSH_TMP : NLSH_RIN, NLSH_QIN(0));
 }
+#undef NLSH_QBLK
+#undef NLSH_QIN
+#undef NLSH_TMP
+#undef NLSH_RIN
 
 // One k-block (nchunk 16-byte chunks of every row, LDS row stride RSt slots) for a wave that holds NQ queries, on NT
 // 64-row tiles.  Blocks = (chunk, tile) pairs in chunk-major order; two chunks are unrolled so that the row-chunk
 // registers (rr[0], rr[1]) and the query sets (qa, qb) alternate statically: block j reads rr[j & 1] while the row
 // chunk of block j + 1 is on its way into rr[(j + 1) & 1], and the query chunk c + 1 is requested during the first block
-// of chunk c.
+// of chunk c.  The main loop has NO branch but its back edge: prefetches past the end of the k-block are clamped to its
+// last chunk (valid addresses, values unused) instead of being guarded -- guarded, the loop carried 8 branches, 22
+// scalar-ALU instructions and 25 s_nops per 384 VALU, and on this machine instruction issue is what the kernel is
+// bound by (r02: kernel time tracks VALU x 2.3 + scalar x 2..4 cycles per SIMD across every variant measured).
 template <int NQ, int NT>
 __device__ __forceinline__ void l2_kblock(const float4 *col, int RSt, int nchunk, const const_f32p (&qk)[4], float (&acc)[4][4]) {
     QSet qa, qb;
     float4 rr[2];
     const int TS = 64 * RSt;   // tile stride in float4 slots
+    const int last = nchunk - 1;
     rr[0] = col[0];
     load_qset<NQ>(qa, qk, 0, 0.0f);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    for (int c = 0; c < nchunk; c += 2) {
-        const bool has1 = c + 1 < nchunk, has2 = c + 2 < nchunk;
+    int c = 0;
+    for (; c + 1 < nchunk; c += 2) {
+        const int c2 = min(c + 2, last);   // first chunk of the next pair (clamped on the last pair)
 #pragma unroll
         for (int j = 0; j < 2 * NT; ++j) {
             const int tl = j % NT, cc = j / NT;             // compile-time after unrolling
-            if (cc == 1 && tl == 0 && !has1) break;        // odd chunk count: the pair's second chunk does not exist
             const int jn = j + 1, tn = jn % NT, cn = jn / NT;
-            if (cn == 0 || (cn == 1 && has1) || (cn == 2 && has2)) rr[jn & 1] = col[tn * TS + c + cn];
+            rr[jn & 1] = col[tn * TS + (cn == 2 ? c2 : c + cn)];
             if (tl == 0) {
-                if (cc == 0 && has1) load_qset<NQ>(qb, qk, 16 * (c + 1), rr[j & 1].x);
-                if (cc == 1 && has2) load_qset<NQ>(qa, qk, 16 * (c + 2), rr[j & 1].x);
+                if (cc == 0) load_qset<NQ>(qb, qk, 16 * (c + 1), rr[j & 1].x);
+                else load_qset<NQ>(qa, qk, 16 * c2, rr[j & 1].x);
             }
             __builtin_amdgcn_sched_barrier(0);
             l2_tile_block<NQ>(acc[tl], rr[j & 1], cc ? qb : qa);
             if (tl == NT - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the next chunk's queries (and first row chunk)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (c < nchunk) {   // odd chunk count (d / 4 not a multiple of the stage width): one more chunk, queries in qa, tile 0 in rr[0]
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (j + 1 < NT) rr[(j + 1) & 1] = col[(j + 1) * TS + c];
+            __builtin_amdgcn_sched_barrier(0);
+            l2_tile_block<NQ>(acc[j], rr[j & 1], qa);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
