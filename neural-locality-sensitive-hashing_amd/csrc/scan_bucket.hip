@@ -896,7 +896,6 @@ __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
     if (q >= a.Q) return;
     int nk = __builtin_amdgcn_readfirstlane(a.nkeys[q]);
     nk = nk < 0 ? 0 : (nk > a.P ? a.P : nk);
-    uint64_t top = KEY_NONE, tau = KEY_NONE;
     // lane p holds probe p's record (written by bscatter): where its partial lists are
     int ns_l = 0, j_l = 0, ng_l = 0;
     long long t0_l = 0;
@@ -913,8 +912,8 @@ __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
         if (lane == 0) a.out_ncand[q] = c;
     }
     // The query's partial lists (one per probe and row segment) are numbered 0..L-1 by an inclusive scan of the
-    // per-probe segment counts.  R = 64/k lists are fetched per round with ONE load instruction (lane -> (list,
-    // entry)): L/R dependent memory round trips instead of L, which is what this kernel's time was.
+    // per-probe segment counts.  A round fetches 3 x R lists (R = 64/k per load instruction: lane -> (list, entry)) and
+    // SELECTS the k best of them and the best so far (merge_round); typical queries (<= 18 lists at k = 10) take one round.
     int incl = ns_l;
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
@@ -924,25 +923,32 @@ __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
     const int L = __builtin_amdgcn_readlane(incl, 63);
     const int R = 64 / a.k;
     const int r = lane / a.k, e = lane - r * a.k;
-    for (int base = 0; base < L; base += R) {
-        const int li = base + r;
-        int lo = 0, hi = 63;  // probe of list li = first lane whose inclusive count exceeds li
+    __shared__ uint64_t scratch[4][64];
+    uint64_t *sc = scratch[threadIdx.x >> 6];
+    uint64_t carry = KEY_NONE;
+    for (int base = 0; base < L; base += 3 * R) {
+        uint64_t key[4];
+        key[0] = carry;
 #pragma unroll
-        for (int step = 0; step < 6; ++step) {
-            const int mid = (lo + hi) >> 1;
-            if (__shfl(incl, mid) > li) hi = mid; else lo = mid + 1;
+        for (int s = 0; s < 3; ++s) {
+            const int li = base + s * R + r;
+            int lo = 0, hi = 63;  // probe of list li = first lane whose inclusive count exceeds li
+#pragma unroll
+            for (int step = 0; step < 6; ++step) {
+                const int mid = (lo + hi) >> 1;
+                if (__shfl(incl, mid) > li) hi = mid; else lo = mid + 1;
+            }
+            const int p = lo > 63 ? 63 : lo;
+            const int si = li - (__shfl(incl, p) - __shfl(ns_l, p));
+            const long long t = (long long)(((unsigned long long)(unsigned)__shfl((int)(t0_l >> 32), p) << 32) | (unsigned)__shfl((int)t0_l, p)) +
+                                (long long)si * __shfl(ng_l, p);
+            const int j = __shfl(j_l, p);
+            // t >= max_tasks: table overflow, status[1] was set by the scan kernel and the caller repeats the call
+            key[s + 1] = (r < R && li < L && t < a.max_tasks) ? a.partial[(t * a.QB + j) * a.k + e] : KEY_NONE;
         }
-        const int p = lo > 63 ? 63 : lo;
-        const int si = li - (__shfl(incl, p) - __shfl(ns_l, p));
-        const long long t = (long long)(((unsigned long long)(unsigned)__shfl((int)(t0_l >> 32), p) << 32) | (unsigned)__shfl((int)t0_l, p)) +
-                            (long long)si * __shfl(ng_l, p);
-        const int j = __shfl(j_l, p);
-        uint64_t key = KEY_NONE;
-        // t >= max_tasks: table overflow, status[1] was set by the scan kernel and the caller repeats the call
-        if (r < R && li < L && t < a.max_tasks) key = a.partial[(t * a.QB + j) * a.k + e];
-        topk_offer(top, tau, key, a.k, lane);
+        carry = merge_round<4>(key, a.k, lane, sc);
     }
-    store_topk(a.out_dist, a.out_idx, a.out_keys, q, a.k, top, lane);
+    merge_finish(carry, a.k, lane, a.out_dist, a.out_idx, a.out_keys, q);
 }
 
 #ifndef NLSH_TILED_QB

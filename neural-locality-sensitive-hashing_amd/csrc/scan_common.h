@@ -174,6 +174,32 @@ __device__ __forceinline__ uint64_t select_k_smallest(const uint64_t (&key)[NK],
     return n >= k ? ((uint64_t)dk + 1ull) << 32 : KEY_NONE;
 }
 
+// Merging many short lists by SELECTION instead of ordered insertion: a wave keeps its current best k keys unsorted in
+// lanes 0..k-1 (`carry`), takes NK-1 new keys per lane and round, lets select_k_smallest pick the k best of all NK*64 and
+// reads them back from a per-wave LDS scratch (k keys, compacted: real keys first, KEY_NONE after).  The ordered
+// insertion it replaces (topk_offer) cost ~100 instructions per inserted key and the first list of every query inserts
+// all of its k keys.  merge_finish ranks the k survivors (k uniform compare steps) and stores them in ascending order.
+template <int NK>
+__device__ __forceinline__ uint64_t merge_round(uint64_t (&key)[NK], int k, int lane, uint64_t *scratch) {
+    select_k_smallest<NK>(key, k, lane, scratch);
+    return lane < k ? scratch[lane] : KEY_NONE;   // same wave wrote it: LDS operations of a wave complete in order
+}
+
+__device__ __forceinline__ void merge_finish(uint64_t carry, int k, int lane, float *out_dist, int32_t *out_idx, uint64_t *out_keys, long long q) {
+    int rank = 0;
+    for (int j = 0; j < k; ++j) {   // keys are distinct ((distance, id) with distinct ids), KEY_NONE sits behind the real ones
+        const uint64_t kj = read_lane64(carry, j);
+        rank += kj < carry ? 1 : 0;
+    }
+    if (lane < k) {
+        const bool none = carry == KEY_NONE;
+        const int pos = none ? lane : rank;
+        out_dist[q * k + pos] = none ? __builtin_inff() : float_from_mono((uint32_t)(carry >> 32));
+        out_idx[q * k + pos] = none ? -1 : (int32_t)(uint32_t)carry;
+        if (out_keys) out_keys[q * k + pos] = carry;
+    }
+}
+
 __device__ __forceinline__ void store_topk(float *out_dist, int32_t *out_idx, uint64_t *out_keys, long long q, int k,
                                            uint64_t top, int lane) {
     if (lane < k) {

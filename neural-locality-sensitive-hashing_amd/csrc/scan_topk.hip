@@ -222,17 +222,30 @@ __global__ __launch_bounds__(256) void merge_shards_kernel(const uint64_t *keys_
     const int lane = threadIdx.x & 63;
     const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= Q) return;
-    uint64_t top = KEY_NONE, tau = KEY_NONE;
-    int32_t nc = 0;
-    for (int g = 0; g < G; ++g) {
-        const uint64_t *row = keys_in + ((long long)g * Q + q) * row_stride;
-        const uint64_t key = lane < k ? row[lane] : KEY_NONE;
-        topk_offer(top, tau, key, k, lane);
-        if (ncand_in) nc += ncand_in[(long long)g * Q + q];
-        else if (row_stride > k) nc += (int32_t)row[k];
+    // G shard lists of k keys: 3 x (64 / k) lists per round, the k best of them and of the best so far SELECTED
+    // (merge_round), ranked and stored at the end -- no ordered insertion
+    const int R = 64 / k, r = lane / k, e = lane - r * k;
+    __shared__ uint64_t scratch[4][64];
+    uint64_t *sc = scratch[threadIdx.x >> 6];
+    uint64_t carry = KEY_NONE;
+    for (int base = 0; base < G; base += 3 * R) {
+        uint64_t key[4];
+        key[0] = carry;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int g = base + s * R + r;
+            key[s + 1] = (r < R && g < G) ? keys_in[((long long)g * Q + q) * row_stride + e] : KEY_NONE;
+        }
+        carry = merge_round<4>(key, k, lane, sc);
     }
-    store_topk(out_dist, out_idx, nullptr, q, k, top, lane);
-    if (out_ncand && (ncand_in || row_stride > k) && lane == 0) out_ncand[q] = nc;
+    merge_finish(carry, k, lane, out_dist, out_idx, nullptr, q);
+    if (out_ncand && (ncand_in || row_stride > k)) {
+        int32_t nc = 0;
+        for (int g = lane; g < G; g += 64) nc += ncand_in ? ncand_in[(long long)g * Q + q] : (int32_t)keys_in[((long long)g * Q + q) * row_stride + k];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) nc += __shfl_xor(nc, m);
+        if (lane == 0) out_ncand[q] = nc;
+    }
 }
 
 struct ScanWs {
