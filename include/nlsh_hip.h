@@ -145,6 +145,11 @@ size_t nlsh_scan_workspace(int64_t Q, int P, int k, int64_t max_tasks, int64_t n
  * A query's candidate list is cut into segments of `seg_rows` rows (0 = default), one wavefront
  * each; max_tasks bounds the number of segments the workspace holds: if status[1] != 0 the
  * results are incomplete and the call must be repeated with max_tasks >= status[0].
+ * Workspace contract of the bucket-major schedules (algo 1, 2): the per-bucket pair counters live in the first
+ * 4 * n_buckets bytes of the workspace (an offset that does not depend on Q, P or max_tasks).  Those bytes must be ZERO
+ * before the first call that uses the buffer and must not be written by anything else afterwards (do not lend the buffer
+ * to algo 0 calls in between); every completed call leaves them zero again (the scatter step hands every count back),
+ * which is what saves a clearing launch per batch.
  * ev_scan_begin / ev_scan_end (nullable hipEvent_t): recorded on `stream` immediately before and
  * after the scan kernel, so a caller can time the HBM-bound kernel alone (bench.py roofline).
  * Limits: d <= NLSH_MAX_DIM, k <= NLSH_MAX_K, P <= NLSH_MAX_PROBES. */

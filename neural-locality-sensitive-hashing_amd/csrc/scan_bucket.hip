@@ -104,16 +104,6 @@ struct BArgs {
     int d4p;
 };
 
-// one launch instead of five hipMemsetAsync nodes (4.8 us each on this runtime): shared bounds to KEY_NONE,
-// bucket probe counts, cursors and the status words to zero
-__global__ __launch_bounds__(256) void binit_kernel(BArgs a) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < a.Q) a.tauq[i] = KEY_NONE;
-    if (i < a.nb) a.bcount[i] = 0;
-    if (i < 4) a.counters[i] = 0;
-    if (i < 2) a.status[i] = 0;
-}
-
 // Bucket lookup of every (query, probe): binary search of the key in uniq[nb].  The first ~10 of its ~13 steps run on a
 // coarse table in LDS (every `stride`-th key, <= 1024 entries, loaded once per workgroup), the last log2(stride) on the
 // stride-long run in global memory: 3-4 dependent global loads per thread instead of 13.
@@ -123,9 +113,11 @@ __global__ __launch_bounds__(256) void bplan_kernel(BArgs a, int stride) {
     for (int i = threadIdx.x; i < nco; i += 256) coarse[i] = a.uniq[(long long)i * stride];
     __syncthreads();
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx == 0) { a.status[0] = 0; a.status[1] = 0; }   // per-batch initialisation rides along (no separate launch)
     if (idx >= a.Q * a.P) return;
     const long long q = idx / a.P;
     const int p = (int)(idx - q * a.P);
+    if (p == 0) a.tauq[q] = KEY_NONE;        // running bound of the query
     int nk = a.nkeys[q];
     nk = nk < 0 ? 0 : (nk > a.P ? a.P : nk);
     int b = -1;
@@ -231,7 +223,7 @@ __global__ __launch_bounds__(256) void bscan_kernel(BArgs a) {
         a.pairoff[b] = po;
         a.taskoff[b] = to;
         const int row0 = a.offsets[b];
-        for (int t = 0; t < nt; ++t) {
+        for (int t = 0; t < nt; ++t) {   // (writing a block's tasks with all its threads, one task per thread and round, measured 15.6 us against 9.5 us)
             const long long tt = (long long)to + t;
             if (tt >= a.max_tasks) break;
             // segment-major: the query groups of one row segment get consecutive task ids, so they run
@@ -966,10 +958,10 @@ struct BWs {
 static void blayout(long long Q, int P, int k, long long max_tasks, long long nb, int d, bool tiled, BWs *w) {
     size_t o = 0;
     const size_t qp = (size_t)Q * P * 4, nb4 = (size_t)(nb > 0 ? nb : 1) * 4;
+    w->bcount = o;   o += ws_align(nb4);   // first, at an offset that does not depend on the batch: ZERO between calls (workspace contract)
     w->pbkt = o;     o += ws_align(qp);
     w->prec = o;     o += ws_align(qp * 4);
     w->inv_q = o;    o += ws_align(qp);
-    w->bcount = o;   o += ws_align(nb4);
     w->pairoff = o;  o += ws_align(nb4);
     w->taskoff = o;  o += ws_align(nb4);
     w->bgroups = o;  o += ws_align(nb4);
@@ -1022,12 +1014,14 @@ int bucket_scan_run(const BucketScanCall &c) {
 
     hipStream_t s = c.stream;
     if (c.phases & NLSH_PHASE_PLAN) {
-        long long n_init = c.Q > c.nb ? c.Q : c.nb;
-        if (n_init < 8) n_init = 8;
-        hipLaunchKernelGGL(binit_kernel, dim3((unsigned)((n_init + 255) / 256)), dim3(256), 0, s, a);
         const unsigned gp = (unsigned)((c.Q * c.P + 255) / 256);
         int stride = 1;
         while ((long long)stride * 1024 < c.nb) stride <<= 1;  // coarse table of bplan: <= 1024 entries
+        // Four launches.  (One fused launch with grid barriers between the steps of this counting sort was built and
+        // measured in r02: 127 us with agent-scope fences -- each writes back / invalidates an XCD's L2 --, 63 us with
+        // device-coherent sc1 accesses instead, against 35 us for the separate launches: crossing XCDs inside a kernel
+        // costs as much as a kernel boundary on this part.)  The per-bucket pair counters need no clearing launch: the
+        // scatter step hands every count back, so they are zero again after every call (workspace contract, nlsh_hip.h).
         hipLaunchKernelGGL(bplan_kernel, dim3(gp), dim3(256), 0, s, a, stride);
         if (c.nb > 0) {
             const unsigned gb = (unsigned)((c.nb + 255) / 256);

@@ -257,9 +257,12 @@ class Indexer:
             max_tasks = self._max_tasks[tkey]
             ws_bytes = L.nlsh_scan_workspace(Q, P, k, max_tasks, self.n_buckets, d)
             stream = _stream(dev)
-            ws = self._ws.get(stream)
+            # one workspace per stream and schedule family: the bucket-major PLAN phase keeps its per-bucket counters at the
+            # head of the workspace ZERO between calls (include/nlsh_hip.h), so nothing else may write there
+            wkey = (stream, algo != _capi.SCAN_QUERY_MAJOR)
+            ws = self._ws.get(wkey)
             if ws is None or ws.numel() < ws_bytes or ws.device != dev:
-                ws = self._ws[stream] = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
+                ws = self._ws[wkey] = torch.zeros((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
             self._scan_launch(q, keys, nkeys, k, algo, max_tasks, out_dist, out_idx, out_keys, ncand, status, ws,
                               _capi.PHASE_ALL, events)
             if not check or Q == 0:
@@ -267,11 +270,15 @@ class Indexer:
             needed, overflow = status.cpu().tolist()
             if not overflow:
                 break
-            self._max_tasks[tkey] = int(needed * 1.25) + 1024      # segment table too small: grow and repeat
+            self._grow_or_raise(tkey, needed, overflow, wkey)       # segment table too small: grow and repeat
         self.last_status = status
         self.last_algo = algo
-        self._last_pack, self._last_tkey = pack, tkey
+        self._last_pack, self._last_tkey, self._last_wkey = pack, tkey, wkey
         return out_dist, out_idx, ncand, out_keys
+
+    def _grow_or_raise(self, tkey, needed, flag, wkey):
+        """status[1] != 0: the task table was too small; grow it, the caller repeats the call."""
+        self._max_tasks[tkey] = int(needed * 1.25) + 1024
 
     def _scan_args(self, Q, d, keys, nkeys, k, algo, max_tasks, out_dist, out_idx, out_keys, ncand, status, ws):
         """The arguments of `nlsh_scan_topk_phase` that do not change between batches of one shape, as plain ints:
@@ -356,7 +363,7 @@ class Indexer:
             needed, overflow = int(host[n - 2]), int(host[n - 1])
             if not overflow or Q == 0:
                 return (host[:Q * k].reshape(Q, k), host[Q * k:Q * k + Q], host[n:n + Q * P].reshape(Q, P), host[n + Q * P:n + nk])
-            self._max_tasks[tkey] = int(needed * 1.25) + 1024
+            self._grow_or_raise(tkey, needed, overflow, self._last_wkey)
 
     @staticmethod
     def _plain_lists(idx_h, nc_h):

@@ -72,7 +72,7 @@ class QueryPipeline:
             s.out_keys = torch.empty((self.Q, k), dtype=torch.int64, device=dev) if (want_keys or exchange) else None
             s.ncand = torch.empty((self.Q,), dtype=torch.int32, device=dev)
             s.status = torch.zeros((2,), dtype=torch.int32, device=dev)
-            s.ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
+            s.ws = torch.zeros((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)   # PLAN-phase head must start out zero (include/nlsh_hip.h)
             s.planned, s.scanned, s.done = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
             s.done.record(torch.cuda.current_stream(dev))
             # everything about the slot's launches that does not change from batch to batch, as plain ints: a submit is
