@@ -285,6 +285,25 @@ def main():
     assert overflow == 0 and not (pipe is not None and pipe.overflowed()), "segment table overflow inside the timed region"
     scan_avg_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
+    # N=1: the same K device-resident steps through the three-stage pipeline as well (what a serving loop would run; the
+    # sequential region above is the one whose scan kernel is timed alone on the chip for the roofline)
+    piped_qps = None
+    if world == 1 and pipe is None:
+        from nlsh_amd.pipeline import QueryPipeline
+        alt = QueryPipeline(indexer, qb[0], k=k, hash_times=P, depth=3)
+        for i in range(warmup):
+            alt.submit(qb[i % B], seed=1000 + i)
+        alt.synchronize()
+        fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            alt.submit(qb[i % B], seed=1000 + i)
+        alt.synchronize()
+        fence()
+        piped_qps = Q * steps / (time.perf_counter() - t0)
+        assert not alt.overflowed()
+        del alt
+
     # candidates per launch of the timed device steps (untimed recomputation with the same batches and probe seeds)
     sum_c = []
     for i in range(steps):
@@ -379,6 +398,7 @@ def main():
                               ("" if world == 1 else f"; sharded: every rank scans all queries over its shard and returns the lists of its 1/{world} slice of the batch"),
             "protocol_median_qps": Q / float(np.median(call_s)),
             "device_resident_qps": Q * steps / elapsed_dev, "device_resident_ms_per_step": 1e3 * elapsed_dev / steps,
+            "device_resident_pipelined_qps": piped_qps,
             "config": {"workload": f"{wl['cfg']}, N={N} d={d} Q={Q} H={H} k={k} hash_times={P}, {B} query batches in rotation",
                        "hash": hash_desc,
                        "parallelism": (f"corpus {args.shard} sharded x{world} ({indexer._candidate_vectors_gpu.shape[0]} rows on rank 0), "
