@@ -197,7 +197,8 @@ def _all_to_all_rows(send: torch.Tensor, send_counts, recv_counts, group) -> tor
 def exchange_rows_by_bucket(local_rows: torch.Tensor, local_keys: torch.Tensor, id_base: int, group=None):
     """Build-time exchange of the bucket partition.  In: this rank's contiguous row range `[n_r, d]`, its
     bucket keys (int32 [n_r]) and the global id of its first row.  Out: (rows this rank OWNS [m_r, d], their
-    global ids int32 [m_r] ascending within a bucket, (size-biased bucket, N) of the whole corpus).
+    global ids int32 [m_r] ascending within a bucket, (size-biased bucket, N) of the whole corpus, the bucket keys of
+    ALL corpus rows in global row order -- the all-gather every rank already paid for).
     Collectives: one all-gather of the keys, one of the [G] send counts, two all-to-alls (rows, ids)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     keys_all = _all_gather_rows(local_keys.view(-1), group)
@@ -215,19 +216,19 @@ def exchange_rows_by_bucket(local_rows: torch.Tensor, local_keys: torch.Tensor, 
         send_counts = send_counts.cpu().tolist()
         rows = _all_to_all_rows(local_rows[order], send_counts, recv_counts, group)
         ids = _all_to_all_rows(ids_local[order], send_counts, recv_counts, group)
-        return rows, ids, stats
+        return rows, ids, stats, keys_all
     # fallback (NLSH_SHARD_EXCHANGE=allgather): every rank gathers all rows and keeps the ones it owns -- G times the
     # traffic of the all-to-all, the same rows in the same (ascending global id) order
     mine = torch.nonzero(owner_all == rank).view(-1)
     rows = _all_gather_rows(local_rows, group)[mine]
     ids = _all_gather_rows(ids_local, group)[mine]
-    return rows, ids, stats
+    return rows, ids, stats, keys_all
 
 
-def global_statistics(local_keys: torch.Tensor, group=None) -> Tuple[float, float]:
-    """Whole-corpus schedule statistics for the row partition (one all-gather of the keys)."""
+def global_statistics(local_keys: torch.Tensor, group=None):
+    """Whole-corpus schedule statistics for the row partition (one all-gather of the keys) + the gathered keys."""
     keys_all = _all_gather_rows(local_keys.view(-1), group)
-    return corpus_statistics(torch.unique(keys_all, return_counts=True)[1])
+    return corpus_statistics(torch.unique(keys_all, return_counts=True)[1]), keys_all
 
 
 class ShardedIndexer:
@@ -243,16 +244,39 @@ class ShardedIndexer:
         self.group = group
         self.shard = shard
         world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._directory = None      # host CSR of ALL buckets (global row ids), built lazily from keys_all for the F7 rule
         if world == 1:
             self.local = Indexer(hashing, local_corpus_gpu, distance_func, id_base=id_base, **kw)
+            self.keys_all = None
             return
         keys, _ = hashing.hash_device(local_corpus_gpu, n=1)       # same launch the index build uses (indexer.py:36-38)
         if shard == "buckets":
-            rows, ids, stats = exchange_rows_by_bucket(local_corpus_gpu, keys.view(-1), id_base, group)
+            rows, ids, stats, self.keys_all = exchange_rows_by_bucket(local_corpus_gpu, keys.view(-1), id_base, group)
             self.local = Indexer(hashing, rows, distance_func, row_ids=ids, schedule_stats=stats, **kw)
         else:
-            stats = global_statistics(keys.view(-1), group)
+            stats, self.keys_all = global_statistics(keys.view(-1), group)
             self.local = Indexer(hashing, local_corpus_gpu, distance_func, id_base=id_base, schedule_stats=stats, **kw)
+
+    def rows_of_key(self, key):
+        """Ascending GLOBAL row ids of one bucket of the WHOLE corpus ([] for an unknown key), answered locally on every
+        rank: the build-time all-gather left every rank the bucket key of every corpus row (4 B per row), so the F7 rule
+        of the rare short queries (nlsh/indexer.py:91-93: rows of the last key) needs no collective at query time."""
+        import numpy as np
+        if self.keys_all is None:
+            return self.local._rows_of_key(key)
+        if self._directory is None:
+            kh = self.keys_all.cpu().numpy()
+            order = np.argsort(kh, kind="stable")
+            uniq, first = np.unique(kh[order], return_index=True)
+            self._directory = (uniq, np.append(first, len(kh)), order)
+        uniq, offs, order = self._directory
+        key = int(key)
+        if self.local._hashing.key_mode == _capi.KEY_FULL and key >= (1 << 31):
+            key -= 1 << 32
+        i = int(np.searchsorted(uniq, key))
+        if i >= len(uniq) or int(uniq[i]) != key:
+            return []
+        return order[offs[i]:offs[i + 1]].tolist()
 
     def query_tensors(self, query_vectors, k=10, hash_times=10, seed=0, check=True, events=None):
         """`seed` must be the same on every rank (default 0; pass a per-step value to vary probes)."""
@@ -288,27 +312,18 @@ class ShardedIndexer:
         lo, hi = shard_range(Q, rank, world) if own_slice else (0, Q)
         idx_h, nc_h = idx[lo:hi].cpu().numpy(), nc[lo:hi].cpu().numpy()
         results, counts = local._plain_lists(idx_h, nc_h)                        # short lists are replaced below
-        # queries with fewer than k candidates (rare): which ones is known from the MERGED counts, identical on every rank,
-        # so the pooled F7 lookup below is entered by all ranks or by none, whoever owns the slice
-        nc_all = nc_h if not own_slice else nc.cpu().numpy()
-        short_all = np.nonzero(nc_all < k)[0]
-        if short_all.size:
-            if local.compat:
-                from .hashings import keys_to_sets
-                sel = torch.as_tensor(short_all, device=keys.device)
-                sets = keys_to_sets(keys[sel], nkeys[sel], local._hashing.key_mode)
-                # F7 (indexer.py:91-93): rows of the LAST key of the set; the bucket lives on one rank (bucket partition)
-                # or is split over all (row partition), so the ranks pool their parts
-                mine = [local._rows_of_key(list(s_)[-1]) if s_ else [] for s_ in sets]
-                if world > 1:
-                    pooled = [None] * world
-                    dist.all_gather_object(pooled, mine, group=self.group)
-                    mine = [sorted(sum((p[i] for p in pooled), [])) for i in range(len(mine))]
-                for qi, rows in zip(short_all.tolist(), mine):
-                    if lo <= qi < hi:
-                        results[qi - lo] = rows
-            else:
-                for qi in short_all.tolist():
-                    if lo <= qi < hi:
-                        results[qi - lo] = [int(v) for v in idx_h[qi - lo] if v >= 0]
+        # queries with fewer than k candidates (rare)
+        short = np.nonzero(nc_h < k)[0]
+        if short.size and local.compat:
+            # F7 (indexer.py:91-93): rows of the LAST key of the set iteration -- a bucket of the WHOLE corpus, looked up in
+            # the replicated bucket directory (no collective, whichever rank owns the bucket)
+            from .hashings import host_key_set
+            sel = torch.as_tensor(short + lo, device=keys.device)
+            keys_h, nkeys_h = keys[sel].cpu().numpy(), nkeys[sel].cpu().numpy()
+            for j, row, cnt in zip(short.tolist(), keys_h, nkeys_h):
+                ks = host_key_set(row, int(cnt), local._hashing.key_mode)
+                results[j] = self.rows_of_key(list(ks)[-1]) if ks else []
+        elif short.size:
+            for j in short.tolist():
+                results[j] = [int(v) for v in idx_h[j] if v >= 0]
         return results, counts

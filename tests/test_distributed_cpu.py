@@ -104,7 +104,8 @@ def _exchange_worker(rank, world, port, out_dir, mode="alltoall"):
     from nlsh_amd.distributed import exchange_rows_by_bucket, shard_range
     keys_all, rows_all = _exchange_case()
     lo, hi = shard_range(len(keys_all), rank, world)
-    rows, ids, stats = exchange_rows_by_bucket(torch.from_numpy(rows_all[lo:hi]), torch.from_numpy(keys_all[lo:hi]), lo)
+    rows, ids, stats, gathered = exchange_rows_by_bucket(torch.from_numpy(rows_all[lo:hi]), torch.from_numpy(keys_all[lo:hi]), lo)
+    assert np.array_equal(gathered.numpy(), keys_all)                                 # every rank holds the key of every corpus row
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rows=rows.numpy(), ids=ids.numpy(), stats=np.asarray(stats))
     dist.barrier()
     dist.destroy_process_group()
