@@ -64,7 +64,10 @@ def _worker(rank, world, port, shard, out_dir):
     qlo, qhi = shard_range(len(batches[0]), rank, world)
     assert lists_own == lists_all[qlo:qhi] and nc_own == nc_all[qlo:qhi]
     import json
-    json.dump({"ids": lists_all, "nc": nc_all}, open(os.path.join(out_dir, f"lists{rank}.json"), "w"))
+    # the replicated bucket directory behind the sharded F7 rule: global rows of any bucket, answered locally on each rank
+    some_keys = sorted(set(sharded.keys_all.cpu().tolist()))[::7]
+    directory = {str(key): sharded.rows_of_key(key) for key in some_keys + [31999]}
+    json.dump({"ids": lists_all, "nc": nc_all, "directory": directory}, open(os.path.join(out_dir, f"lists{rank}.json"), "w"))
     if rank == 0:
         np.savez(os.path.join(out_dir, "merged.npz"), **{f"{tag}{i}_{j}": a for tag, res in (("d", direct), ("p", piped))
                                                          for i, r in enumerate(res) for j, a in enumerate(r)},
@@ -99,6 +102,9 @@ def test_two_rank_sharded_pipeline_equals_single_index(tmp_path, shard):
     want, want_nc, _, _ = single.query_with_keys(qd0, single.hash(qd0, hash_times=6) and
                                                  [list(s_) for s_ in __import__("nlsh_amd.hashings", fromlist=["keys_to_sets"]).keys_to_sets(keys, nkeys)], k=10)
     assert l0["nc"] == want_nc and l0["ids"] == want
+    i2r = {int(key): rows.cpu().tolist() for key, rows in single.index2row.items()}
+    assert len(l0["directory"]) > 10 and l0["directory"]["31999"] == []
+    assert all(rows == i2r.get(int(key), []) for key, rows in l0["directory"].items())
 
 
 def test_bench_gpus_2_self_launch_reports_two_ranks():
