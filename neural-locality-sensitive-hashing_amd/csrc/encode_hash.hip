@@ -188,7 +188,8 @@ __global__ __launch_bounds__(NW * 64) void encode_hash_kernel(EncArgs a) {
                 // B fragments ride a ring of four registers, fetched THREE k-chunks (24 MFMAs) ahead of their use
                 // (r02: a ring of eight / seven chunks ahead measured 2.25 ms per 1M rows and 49.7 us per 10k queries against
                 // 2.2 ms / 44 us -- the ring is not what the MFMA pipe waits for; a 64-row SINGLE image for index builds needs
-                // 172 VGPRs, so two workgroups per CU only fit with 42 spilled registers: 2.41 ms).
+                // 172 VGPRs, so two workgroups per CU only fit with 42 spilled registers: 2.41 ms; the next layer's first three
+                // fragments requested before the write-back and barrier of the current one: 2.23 ms / 42.5 us, noise).
                 // The ring is indexed statically (main loop unrolled by 4, branch-free: indices past the end are
                 // clamped and their data unused), so neither a register rotation nor a control-flow join makes
                 // the compiler wait for the youngest load; A fragments (LDS) are fetched one chunk ahead.

@@ -21,7 +21,7 @@ H = 16
 names = ["stage", "layer1", "layer2", "(l3)", "(l4)", "(l5)", "layer_out", "sigmoid", "probes", "dedup+store"]
 for rep in range(3):
     z = torch.zeros((n, H), dtype=torch.float32, device="cuda")
-    hashing._run(x, 10, z_out=z, seed=rep)
+    hashing._run(x, int(sys.argv[2]) if len(sys.argv) > 2 else 10, z_out=z, seed=rep)
     torch.cuda.synchronize()
     st = z.cpu().numpy().reshape(-1)[: (n // 64) * 64 * H].reshape(n // 64, 64 * H)[:, :11]
     d = np.diff(st, axis=1)
