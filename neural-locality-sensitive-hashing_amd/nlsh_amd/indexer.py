@@ -263,20 +263,24 @@ class Indexer:
             ws = self._ws.get(wkey)
             if ws is None or ws.numel() < ws_bytes or ws.device != dev:
                 ws = self._ws[wkey] = torch.zeros((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
-            self._scan_launch(q, keys, nkeys, k, algo, max_tasks, out_dist, out_idx, out_keys, ncand, status, ws,
-                              _capi.PHASE_ALL, events)
+            try:
+                self._scan_launch(q, keys, nkeys, k, algo, max_tasks, out_dist, out_idx, out_keys, ncand, status, ws,
+                                  _capi.PHASE_ALL, events)
+            except _capi.NlshHipError:
+                self._ws.pop(wkey, None)    # a call that failed part-way may have left the counters at the head non-zero
+                raise
             if not check or Q == 0:
                 break
             needed, overflow = status.cpu().tolist()
             if not overflow:
                 break
-            self._grow_or_raise(tkey, needed, overflow, wkey)       # segment table too small: grow and repeat
+            self._grow_task_table(tkey, needed)                     # segment table too small: grow and repeat
         self.last_status = status
         self.last_algo = algo
-        self._last_pack, self._last_tkey, self._last_wkey = pack, tkey, wkey
+        self._last_pack, self._last_tkey = pack, tkey
         return out_dist, out_idx, ncand, out_keys
 
-    def _grow_or_raise(self, tkey, needed, flag, wkey):
+    def _grow_task_table(self, tkey, needed):
         """status[1] != 0: the task table was too small; grow it, the caller repeats the call."""
         self._max_tasks[tkey] = int(needed * 1.25) + 1024
 
@@ -363,7 +367,7 @@ class Indexer:
             needed, overflow = int(host[n - 2]), int(host[n - 1])
             if not overflow or Q == 0:
                 return (host[:Q * k].reshape(Q, k), host[Q * k:Q * k + Q], host[n:n + Q * P].reshape(Q, P), host[n + Q * P:n + nk])
-            self._grow_or_raise(tkey, needed, overflow, self._last_wkey)
+            self._grow_task_table(tkey, needed)
 
     @staticmethod
     def _plain_lists(idx_h, nc_h):

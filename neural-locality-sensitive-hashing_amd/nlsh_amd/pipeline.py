@@ -23,6 +23,8 @@ memory to a later allocation until those streams have passed the batch -- the ca
 must not OVERWRITE it in place before `synchronize()` (or the batch's results) say the batch is done.  The packed
 encoder weights are owned by the pipeline (a reference is held) and re-read from the hasher whenever its parameters
 changed since the last submit (a training step, `load_state`, a device move), so slots never keep a dangling pointer.
+A submit that raises leaves its slot's workspace in an undefined state (the PLAN phase keeps counters at its head zero
+between calls, include/nlsh_hip.h): build a new pipeline after an error.
 """
 from typing import Callable, Optional
 
