@@ -259,50 +259,55 @@ __global__ __launch_bounds__(NW * 64) void encode_hash_kernel(EncArgs a) {
             if (!SINGLE) { float *t = in; in = out; out = t; }
             ENC_STAMP(2 + (l < 4 ? l : 4));
         } else {
-            // output layer: H <= 32 -> one column tile; one row tile per wavefront
-            if (wave < RT) {
-                f32x16 acc;
+            // output layer: H <= 32 columns.  r01 ran it as ONE 32x32x2 column tile per 32-row tile on `RT` of the NW waves
+            // (5 us of a 37-us workgroup with six of eight waves idle and, at H = 16, half of every MFMA's columns
+            // padding).  r02: 16x16x4 tiles -- (M / 16) row tiles x (H / 16) column tiles dealt over ALL waves; same
+            // k-ascending fmaf chain (guide, FP32-input MFMA), so z keeps its bits.  Lane l holds A[row l & 15][k = l >> 4] and
+            // B[k = l >> 4][col l & 15]; with the even/odd de-interleaved LDS rows the two A values of an 8-wide k chunk sit
+            // two floats apart (pos(8c + g) and pos(8c + 4 + g)); B is packed per 16 k (4 MFMA steps) as one float4 per lane.
+            {
+                typedef float f32x4v __attribute__((ext_vector_type(4)));
+                const int ct16 = (a.H + 15) >> 4, ngr = (L.K + 15) >> 4;
+                const int T = (M >> 4) * ct16;
+                const int g = lane >> 4, l16 = lane & 15;
+                const int pa = ((g & 1) << 2) + (g >> 1);   // pos(g) inside a chunk; pos(4 + g) = pa + 2
+                // T <= NW always (M <= 64 rows, H <= 32): a wave owns at most one tile
+                const int t = wave;
+                const int rt = t / ct16, ct = t - rt * ct16;
+                f32x4v acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (t < T) {
+                    const float4 *w0 = Wp + (size_t)ct * ngr * 64 + lane;
+                    const float *arow = in + (size_t)(rt * 16 + l16) * S + pa;
+                    constexpr int OR = 8;   // B ring: groups of 16 k in flight (each is only 4 short MFMAs of cover)
+                    float4 B[OR];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-                const float4 *w0 = Wp + lane;
-                const float *arow = in + (size_t)(wave * 32 + lr) * S + 4 * lh;
-                float4 B[4];  // same ring as the hidden layers
+                    for (int j = 0; j < OR; ++j) B[j] = w0[(size_t)min(j, ngr - 1) * 64];
+                    for (int j0 = 0; j0 < ngr; j0 += OR) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) B[j] = w0[(size_t)min(j, nch - 1) * 64];
-                float4 an = *reinterpret_cast<const float4 *>(arow);
-                const int nch4 = nch & ~3;
-                for (int c = 0; c < nch4; c += 4) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int cc = c + j;
-                        B[(j + 3) & 3] = w0[(size_t)min(cc + 3, nch - 1) * 64];
-                        const float4 av = an;
-                        an = *reinterpret_cast<const float4 *>(arow + min(cc + 1, nch - 1) * 8);
-                        __builtin_amdgcn_sched_barrier(0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, B[j].x, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, B[j].y, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, B[j].z, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, B[j].w, acc, 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
+                        for (int jj = 0; jj < OR; ++jj) {
+                            const int j = j0 + jj;
+                            if (j < ngr) {
+                                const float4 bq = B[jj];
+                                if (j + OR < ngr) B[jj] = w0[(size_t)(j + OR) * 64];
+                                const int c0 = 2 * j, c1 = 2 * j + 1;
+                                const float a0 = arow[c0 * 8], a1 = arow[c0 * 8 + 2];
+                                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bq.x, acc, 0, 0, 0);
+                                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bq.y, acc, 0, 0, 0);
+                                if (c1 < nch) {   // Kp is a multiple of 8, not of 16: the last group may hold one chunk only
+                                    const float a2 = arow[c1 * 8], a3 = arow[c1 * 8 + 2];
+                                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bq.z, acc, 0, 0, 0);
+                                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bq.w, acc, 0, 0, 0);
+                                }
+                            }
+                        }
                     }
                 }
+                if (SINGLE) __syncthreads();   // one image: z lands on activation rows other waves were still reading
+                if (t < T) {
+                    const int col = ct * 16 + l16;
+                    const float bias = Bp[col];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int cc = nch4 + j;
-                    if (cc < nch) {
-                        const float4 av = an;
-                        an = *reinterpret_cast<const float4 *>(arow + min(cc + 1, nch - 1) * 8);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, B[j].x, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, B[j].y, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, B[j].z, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, B[j].w, acc, 0, 0, 0);
-                    }
-                }
-                const float bias = Bp[lr];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int row = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-                    out[row * 33 + lr] = acc[i] + bias;  // z, natural column order
+                    for (int i = 0; i < 4; ++i) out[(rt * 16 + 4 * g + i) * 33 + col] = acc[i] + bias;  // z, natural column order
                 }
             }
             __syncthreads();
@@ -334,6 +339,9 @@ __global__ __launch_bounds__(NW * 64) void encode_hash_kernel(EncArgs a) {
     }
     __syncthreads();
     ENC_STAMP(8);
+    // (r02 measured a parallel form of this epilogue -- a thread per (row, probe, 4-bit word) OR-ing its bits into the code,
+    // de-duplication by a thread per (row, probe) with first-occurrence flags -- at 38.8 us per 10k queries against 37.5 us:
+    // four more passes and barriers cost what the idle threads had cost.)
     // [M][n_probes] key table: over z (dead now) in the ping-pong form, behind z and p in the single image
     int32_t *kbuf = reinterpret_cast<int32_t *>(SINGLE ? smem + 2 * M * 33 : out);
     const int NP = a.n_probes;
@@ -403,6 +411,20 @@ __global__ void pack_weights_kernel(const float *W, const float *b, int K, int N
         bdst[e] = (b != nullptr && e < N) ? b[e] : 0.0f;
 }
 
+// output layer, 16x16x4 order: packed[((ct*ngr + j)*64 + lane)*4 + s] = W[ct*16 + (lane&15)][16j + 4s + (lane>>4)]
+__global__ void pack_out_weights_kernel(const float *W, const float *b, int K, int N, int ngr, int ct16, int Np, float *wdst, float *bdst) {
+    const long long total = (long long)ct16 * ngr * 256;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int st = (int)(e & 3), lane = (int)((e >> 2) & 63);
+        const long long rest = e >> 8;
+        const int j = (int)(rest % ngr), ct = (int)(rest / ngr);
+        const int col = ct * 16 + (lane & 15), k = 16 * j + 4 * st + (lane >> 4);
+        wdst[e] = (col < N && k < K) ? W[(size_t)col * K + k] : 0.0f;
+    }
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < Np; e += (long long)gridDim.x * blockDim.x)
+        bdst[e] = (b != nullptr && e < N) ? b[e] : 0.0f;
+}
+
 // nlsh/utils.pyx:6-15: out = (out << 1) | bit over H bits, returned as int16 (or untruncated)
 __global__ void pack_codes_kernel(const int32_t *codes, long long total, int H, int key_mode, int32_t *keys) {
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
@@ -421,7 +443,10 @@ static int fill_layers(int n_layers, const int *dims, LayerDesc *L, long long *t
         L[l].Kp = round_up(dims[l], 8);
         L[l].Np = round_up(dims[l + 1], 32);
         L[l].w_off = off;
-        off += (long long)L[l].Np * L[l].Kp;
+        // hidden layers: [Np/32 column tiles][Kp/8 chunks][64 lanes][4]; the output layer (l == n_layers - 1) is packed for
+        // 16x16x4 tiles: [ceil(N/16)][ceil(K/16) groups][64][4], which can exceed Np * Kp by one k group
+        const long long hidden = (long long)L[l].Np * L[l].Kp, outl = (long long)((dims[l + 1] + 15) / 16) * ((dims[l] + 15) / 16) * 256;
+        off += (l + 1 == n_layers && outl > hidden) ? outl : hidden;
         L[l].b_off = off;
         off += L[l].Np;
     }
@@ -466,8 +491,12 @@ extern "C" int nlsh_encoder_pack(int n_layers, const int *dims, const float *con
         long long tot = (long long)L[l].Np * L[l].Kp;
         int grid = (int)((tot + 255) / 256);
         if (grid > 4096) grid = 4096;
-        hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, s, W[l], b[l], L[l].K, L[l].N, L[l].Kp, L[l].Np,
-                           packed + L[l].w_off, packed + L[l].b_off);
+        if (l + 1 == n_layers)
+            hipLaunchKernelGGL(pack_out_weights_kernel, dim3(grid), dim3(256), 0, s, W[l], b[l], L[l].K, L[l].N, (L[l].K + 15) / 16,
+                               (L[l].N + 15) / 16, L[l].Np, packed + L[l].w_off, packed + L[l].b_off);
+        else
+            hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, s, W[l], b[l], L[l].K, L[l].N, L[l].Kp, L[l].Np,
+                               packed + L[l].w_off, packed + L[l].b_off);
         NLSH_CHECK_HIP(hipGetLastError());
     }
     return NLSH_OK;
