@@ -70,6 +70,9 @@ __device__ __forceinline__ void philox4x32_10(unsigned long long seed, uint32_t 
 }
 
 // Batches up to this many rows take the single-image 32-row form (2 x 256 CUs x 32 rows: every workgroup resident at once)
+#ifndef NLSH_ENC_BUILD_128
+#define NLSH_ENC_BUILD_128 1  // index-build launches: 1 = 128-row workgroups on one LDS image, 0 = 64-row workgroups on a ping-pong pair
+#endif
 #ifndef NLSH_ENC_SINGLE_MAX_ROWS
 #define NLSH_ENC_SINGLE_MAX_ROWS 16384
 #endif
@@ -271,43 +274,53 @@ __global__ __launch_bounds__(NW * 64) void encode_hash_kernel(EncArgs a) {
                 const int T = (M >> 4) * ct16;
                 const int g = lane >> 4, l16 = lane & 15;
                 const int pa = ((g & 1) << 2) + (g >> 1);   // pos(g) inside a chunk; pos(4 + g) = pa + 2
-                // T <= NW always (M <= 64 rows, H <= 32): a wave owns at most one tile
-                const int t = wave;
-                const int rt = t / ct16, ct = t - rt * ct16;
-                f32x4v acc = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (t < T) {
-                    const float4 *w0 = Wp + (size_t)ct * ngr * 64 + lane;
-                    const float *arow = in + (size_t)(rt * 16 + l16) * S + pa;
-                    constexpr int OR = 8;   // B ring: groups of 16 k in flight (each is only 4 short MFMAs of cover)
-                    float4 B[OR];
+                constexpr int MAXT = (M / 16 * 2 + NW - 1) / NW;   // tiles a wave may own (H <= 32: at most two column tiles)
+                f32x4v accs[MAXT];
 #pragma unroll
-                    for (int j = 0; j < OR; ++j) B[j] = w0[(size_t)min(j, ngr - 1) * 64];
-                    for (int j0 = 0; j0 < ngr; j0 += OR) {
+                for (int m = 0; m < MAXT; ++m) {
+                    const int t = wave + m * NW;
+                    const int rt = t / ct16, ct = t - rt * ct16;
+                    f32x4v acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (t < T) {
+                        const float4 *w0 = Wp + (size_t)ct * ngr * 64 + lane;
+                        const float *arow = in + (size_t)(rt * 16 + l16) * S + pa;
+                        constexpr int OR = 8;   // B ring: groups of 16 k in flight (each is only 4 short MFMAs of cover)
+                        float4 B[OR];
 #pragma unroll
-                        for (int jj = 0; jj < OR; ++jj) {
-                            const int j = j0 + jj;
-                            if (j < ngr) {
-                                const float4 bq = B[jj];
-                                if (j + OR < ngr) B[jj] = w0[(size_t)(j + OR) * 64];
-                                const int c0 = 2 * j, c1 = 2 * j + 1;
-                                const float a0 = arow[c0 * 8], a1 = arow[c0 * 8 + 2];
-                                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bq.x, acc, 0, 0, 0);
-                                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bq.y, acc, 0, 0, 0);
-                                if (c1 < nch) {   // Kp is a multiple of 8, not of 16: the last group may hold one chunk only
-                                    const float a2 = arow[c1 * 8], a3 = arow[c1 * 8 + 2];
-                                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bq.z, acc, 0, 0, 0);
-                                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bq.w, acc, 0, 0, 0);
+                        for (int j = 0; j < OR; ++j) B[j] = w0[(size_t)min(j, ngr - 1) * 64];
+                        for (int j0 = 0; j0 < ngr; j0 += OR) {
+#pragma unroll
+                            for (int jj = 0; jj < OR; ++jj) {
+                                const int j = j0 + jj;
+                                if (j < ngr) {
+                                    const float4 bq = B[jj];
+                                    if (j + OR < ngr) B[jj] = w0[(size_t)(j + OR) * 64];
+                                    const int c0 = 2 * j, c1 = 2 * j + 1;
+                                    const float a0 = arow[c0 * 8], a1 = arow[c0 * 8 + 2];
+                                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bq.x, acc, 0, 0, 0);
+                                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bq.y, acc, 0, 0, 0);
+                                    if (c1 < nch) {   // Kp is a multiple of 8, not of 16: the last group may hold one chunk only
+                                        const float a2 = arow[c1 * 8], a3 = arow[c1 * 8 + 2];
+                                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bq.z, acc, 0, 0, 0);
+                                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bq.w, acc, 0, 0, 0);
+                                    }
                                 }
                             }
                         }
                     }
+                    accs[m] = acc;
                 }
                 if (SINGLE) __syncthreads();   // one image: z lands on activation rows other waves were still reading
-                if (t < T) {
-                    const int col = ct * 16 + l16;
-                    const float bias = Bp[col];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) out[(rt * 16 + 4 * g + i) * 33 + col] = acc[i] + bias;  // z, natural column order
+                for (int m = 0; m < MAXT; ++m) {
+                    const int t = wave + m * NW;
+                    if (t < T) {
+                        const int rt = t / ct16, ct = t - rt * ct16;
+                        const int col = ct * 16 + l16;
+                        const float bias = Bp[col];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) out[(rt * 16 + 4 * g + i) * 33 + col] = accs[m][i] + bias;  // z, natural column order
+                    }
                 }
             }
             __syncthreads();
@@ -563,10 +576,23 @@ extern "C" int nlsh_encode_hash(const float *x, int64_t n, int64_t x_stride, int
             hipLaunchKernelGGL((encode_hash_kernel<1, 8, true, 3>), dim3((unsigned)grid), dim3(512), lds, s, a);
         }
     } else {
-        size_t lds = (size_t)2 * 64 * a.S * 4;
-        NLSH_CHECK_HIP(hipFuncSetAttribute((const void *)encode_hash_kernel<2, 8, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        long long grid = (n + 63) / 64;
-        hipLaunchKernelGGL((encode_hash_kernel<2, 8, false, 1>), dim3((unsigned)grid), dim3(512), lds, s, a);
+        int max_np = 0;
+        for (int l = 0; l + 1 < n_layers; ++l) if (a.L[l].Np > max_np) max_np = a.L[l].Np;
+        if (72 + round_up(n_probes, 8) > maxKp) a.S = 72 + round_up(n_probes, 8) + 4;
+        const size_t lds128 = (size_t)128 * a.S * 4;
+        if (NLSH_ENC_BUILD_128 && max_np <= 32 * 8 && lds128 <= lds_limit) {
+            // index builds: 128 rows per workgroup on ONE image (accumulators of the four row tiles held in registers across the
+            // layer barrier): a B fragment feeds 16 MFMAs instead of 8 and the per-layer fixed cost (write-back, barriers, ring
+            // prologue: ~2.5-3.8 us) is paid once per 128 rows instead of once per 64
+            NLSH_CHECK_HIP(hipFuncSetAttribute((const void *)encode_hash_kernel<4, 8, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128));
+            hipLaunchKernelGGL((encode_hash_kernel<4, 8, true, 1>), dim3((unsigned)((n + 127) / 128)), dim3(512), lds128, s, a);
+        } else {
+            a.S = maxKp + 4;
+            size_t lds = (size_t)2 * 64 * a.S * 4;
+            NLSH_CHECK_HIP(hipFuncSetAttribute((const void *)encode_hash_kernel<2, 8, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            long long grid = (n + 63) / 64;
+            hipLaunchKernelGGL((encode_hash_kernel<2, 8, false, 1>), dim3((unsigned)grid), dim3(512), lds, s, a);
+        }
     }
     NLSH_CHECK_HIP(hipGetLastError());
     return NLSH_OK;
