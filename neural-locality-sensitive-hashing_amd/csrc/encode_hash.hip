@@ -90,8 +90,8 @@ __device__ __forceinline__ void philox4x32_10(unsigned long long seed, uint32_t 
 // With RT = 1 that is 33 KB at width 256 -- small enough to sit on a CU BESIDE six resident workgroups of the scan
 // kernel (20 KB each), which is what lets the batch pipeline (nlsh_amd/pipeline.py) run a query batch's encode under
 // the previous batch's scan; the 133 KB ping-pong form only finds a CU once the scan's dispatch queue has drained.
-template <int RT, int NW, bool SINGLE, int MT = 1>  // MT: column tiles a wave may own in SINGLE mode (1: width <= 32*NW)
-__global__ __launch_bounds__(NW * 64) void encode_hash_kernel(EncArgs a) {
+template <int RT, int NW, bool SINGLE, int MT = 1, int WPE = 1>  // MT: column tiles a wave may own in SINGLE mode (1: width <= 32*NW); WPE: waves per SIMD the registers must allow
+__global__ __launch_bounds__(NW * 64, WPE) void encode_hash_kernel(EncArgs a) {
     constexpr int M = 32 * RT;
     constexpr int NTH = NW * 64;
     extern __shared__ float4 smem4[];
@@ -107,9 +107,12 @@ __global__ __launch_bounds__(NW * 64) void encode_hash_kernel(EncArgs a) {
     const int lh = lane >> 5;   // k parity (A, B) / row-quad select (C)
     const long long row_base = (long long)blockIdx.x * M;
 #ifdef NLSH_ENC_TRACE
-    unsigned long long stamp[12];
+    __shared__ unsigned long long stamp[12];   // LDS, not registers: twelve 64-bit values in thread 0 changed the 128-row form's allocation
 #endif
     ENC_STAMP(0);
+#ifdef NLSH_ENC_TRACE
+    const unsigned long long core0 = __builtin_amdgcn_s_memtime();   // shader-clock counter: with the 100 MHz stamps gives the clock held
+#endif
 
     // ---- stage the input rows (zero padded to Kp, zero rows past n) in the de-interleaved layout
     {
@@ -168,6 +171,10 @@ __global__ __launch_bounds__(NW * 64) void encode_hash_kernel(EncArgs a) {
                 if (col < ncol_keep) {
                     const float bias = Bp[col];
                     const int pc = pos(col);
+                    // opaque copy of the row stride: with the plain S the compiler hoists all 16*RT store addresses out of the
+                    // LAYER loop (they are invariant in SINGLE mode) and spills them -- 32 scratch round trips per write-back
+                    int S = a.S;
+                    asm volatile("" : "+s"(S));
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -253,10 +260,19 @@ __global__ __launch_bounds__(NW * 64) void encode_hash_kernel(EncArgs a) {
                 if (!SINGLE) write_back(nt0, acc);
             }
             if (SINGLE) {
+#ifdef NLSH_ENC_FINE
+                if (l == 1) ENC_STAMP(4);
+#endif
                 __syncthreads();  // every wave has finished reading this layer's input: the image may be overwritten
+#ifdef NLSH_ENC_FINE
+                if (l == 1) ENC_STAMP(5);
+#endif
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
                     if (wave + m * NW < NT) write_back(wave + m * NW, accs[m]);
+#ifdef NLSH_ENC_FINE
+                if (l == 1) ENC_STAMP(6);
+#endif
             }
             __syncthreads();
             if (!SINGLE) { float *t = in; in = out; out = t; }
@@ -403,6 +419,7 @@ __global__ __launch_bounds__(NW * 64) void encode_hash_kernel(EncArgs a) {
     ENC_STAMP(10);
     if (tid == 0 && a.z_out && row_base + M <= a.n)
         for (int i = 0; i <= 10; ++i) a.z_out[row_base * H + i] = (float)(stamp[i] - stamp[0]);
+    if (tid == 0 && a.z_out && row_base + M <= a.n) a.z_out[row_base * H + 11] = (float)(__builtin_amdgcn_s_memtime() - core0);
 #endif
 }
 
@@ -580,7 +597,12 @@ extern "C" int nlsh_encode_hash(const float *x, int64_t n, int64_t x_stride, int
         for (int l = 0; l + 1 < n_layers; ++l) if (a.L[l].Np > max_np) max_np = a.L[l].Np;
         if (72 + round_up(n_probes, 8) > maxKp) a.S = 72 + round_up(n_probes, 8) + 4;
         const size_t lds128 = (size_t)128 * a.S * 4;
-        if (NLSH_ENC_BUILD_128 && max_np <= 32 * 8 && lds128 <= lds_limit) {
+        if (NLSH_ENC_BUILD_128 == 2 && max_np <= 32 * 8) {
+            // two 64-row single-image workgroups per CU (66.5 KB each, 128 VGPRs): one's staging, write-backs and epilogue under the other's MFMAs
+            const size_t lds64 = (size_t)64 * a.S * 4;
+            NLSH_CHECK_HIP(hipFuncSetAttribute((const void *)encode_hash_kernel<2, 8, true, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64));
+            hipLaunchKernelGGL((encode_hash_kernel<2, 8, true, 1, 4>), dim3((unsigned)((n + 63) / 64)), dim3(512), lds64, s, a);
+        } else if (NLSH_ENC_BUILD_128 && max_np <= 32 * 8 && lds128 <= lds_limit) {
             // index builds: 128 rows per workgroup on ONE image (accumulators of the four row tiles held in registers across the
             // layer barrier): a B fragment feeds 16 MFMAs instead of 8 and the per-layer fixed cost (write-back, barriers, ring
             // prologue: ~2.5-3.8 us) is paid once per 128 rows instead of once per 64

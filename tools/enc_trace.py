@@ -18,15 +18,18 @@ Ws, bs = io.load_hasher_weights(os.path.join(ROOT, "neural-locality-sensitive-ha
 hashing = io.hashing_from_weights(Ws, bs, compat=True)
 x = torch.from_numpy(synth.sift_manifold(n, 128, seed=1)).cuda()
 H = 16
+RPW = int(sys.argv[3]) if len(sys.argv) > 3 else 64   # rows per workgroup of the form the launcher picks for n (128: index builds)
 names = ["stage", "layer1", "layer2", "(l3)", "(l4)", "(l5)", "layer_out", "sigmoid", "probes", "dedup+store"]
 for rep in range(3):
     z = torch.zeros((n, H), dtype=torch.float32, device="cuda")
     hashing._run(x, int(sys.argv[2]) if len(sys.argv) > 2 else 10, z_out=z, seed=rep)
     torch.cuda.synchronize()
-    st = z.cpu().numpy().reshape(-1)[: (n // 64) * 64 * H].reshape(n // 64, 64 * H)[:, :11]
+    st = z.cpu().numpy().reshape(-1)[: (n // RPW) * RPW * H].reshape(n // RPW, RPW * H)[:, :12]
+    core = st[:, 11]; st = st[:, :11]
     d = np.diff(st, axis=1)
     keep = [0, 1, 2, 6, 7, 8, 9]
     # stamps 4..6 are unset for a 3-layer encoder: layer_out = stamp7 - stamp3
     d[:, 6] = st[:, 7] - st[:, 3]
+    if os.environ.get("ENC_FINE"): print("fine (layer 2): kloop", (st[:, 4] - st[:, 2]).mean(), "barrier", (st[:, 5] - st[:, 4]).mean(), "writeback", (st[:, 6] - st[:, 5]).mean(), "barrier2", (st[:, 3] - st[:, 6]).mean())
     print(f"rep {rep}: total {st[:, 10].mean():.0f} ticks (100 MHz => {st[:, 10].mean() / 100:.1f} us)  " +
-          "  ".join(f"{names[i]} {d[:, i].mean():.0f}" for i in keep))
+          "  ".join(f"{names[i]} {d[:, i].mean():.0f}" for i in keep) + f"  clock {np.median(core / st[:, 10]) * 0.1:.3f} GHz")
