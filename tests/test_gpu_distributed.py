@@ -125,3 +125,47 @@ def test_bench_gpus_2_self_launch_reports_two_ranks():
     assert rec["scaling"] == "strong" and 0 <= rec["recall_at_10"] <= 1
     assert rec["roofline"]["frac"] <= 1.0 and rec["roofline"]["bound"] in ("valu", "hbm")
     assert "sharded x2" in rec["config"]["parallelism"]
+
+
+def _rccl_worker(rank, port, shard, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)   # "nccl" is RCCL on ROCm
+    corpus, batches, Ws, bs, d, H = _case()
+    from nlsh_amd.data import SIFT
+    from nlsh_amd.distributed import ShardedIndexer, TopkExchange, _exchange_mode
+    from nlsh_amd.indexer import Indexer
+    from nlsh_amd.pipeline import QueryPipeline
+    assert dist.get_backend() == "nccl"
+    mode = _exchange_mode(None)
+    cg = torch.from_numpy(corpus).to(dev)
+    sharded = ShardedIndexer(_hashing(Ws, bs, d, H), cg, SIFT.distance, id_base=0, shard=shard)
+    single = Indexer(_hashing(Ws, bs, d, H), cg, SIFT.distance)
+    k, P = 10, 6
+    qd = [torch.from_numpy(b).to(dev) for b in batches]
+    pipe = QueryPipeline(sharded.local, qd[0], k=k, hash_times=P, depth=3, exchange=TopkExchange(k))
+    for i, b in enumerate(qd):
+        want = single.query_tensors(b, k=k, hash_times=P, seed=70 + i)
+        got = sharded.query_tensors(b, k=k, hash_times=P, seed=70 + i)
+        out = pipe.submit(b, seed=70 + i)
+        pipe.synchronize()
+        for j in range(3):
+            assert torch.equal(got[j], want[j]), (shard, i, j)
+            assert torch.equal(out[j], want[j]), (shard, "pipeline", i, j)
+    lists, nc = sharded.query(qd[0], k=k, hash_times=P, seed=70)
+    lists_own, nc_own = sharded.query(qd[0], k=k, hash_times=P, seed=70, own_slice=True)
+    assert lists_own == lists and nc_own == nc
+    open(os.path.join(out_dir, "ok"), "w").write(f"{mode}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shard", ["buckets", "rows"])
+def test_one_rank_rccl_runs_every_collective_of_the_path(tmp_path, shard):
+    """A one-GPU box cannot hold two RCCL ranks (one rank per device), so this runs the `nccl` backend at world size 1:
+    the build-time exchange (all_reduce of the agreed mode, all_to_all_single with explicit splits), the per-batch
+    all_gather_into_tensor + shard merge, directly and in the pipeline's tail stage -- every RCCL call of the path is
+    issued on device memory once and the results must equal the plain single index."""
+    mp.spawn(_rccl_worker, args=(_free_port(), shard, str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / "ok").exists()
