@@ -140,14 +140,27 @@ def _rccl_worker(rank, port, shard, out_dir):
     assert dist.get_backend() == "nccl"
     mode = _exchange_mode(None)
     cg = torch.from_numpy(corpus).to(dev)
-    sharded = ShardedIndexer(_hashing(Ws, bs, d, H), cg, SIFT.distance, id_base=0, shard=shard)
+    hashing = _hashing(Ws, bs, d, H)
     single = Indexer(_hashing(Ws, bs, d, H), cg, SIFT.distance)
+    sharded = ShardedIndexer(hashing, cg, SIFT.distance, id_base=0, shard=shard)
+    # ShardedIndexer short-cuts the exchange at world size 1: run its build steps by hand so the collectives are issued
+    from nlsh_amd.distributed import exchange_rows_by_bucket, gather_and_merge, global_statistics
+    keys1, _ = hashing.hash_device(cg, n=1)
+    if shard == "buckets":
+        rows, ids, stats, keys_all = exchange_rows_by_bucket(cg, keys1.view(-1), 0)
+        assert mode == "alltoall" and torch.equal(keys_all, keys1.view(-1)) and rows.shape == cg.shape
+        sharded.local = Indexer(hashing, rows, SIFT.distance, row_ids=ids, schedule_stats=stats)
+    else:
+        stats, keys_all = global_statistics(keys1.view(-1))
+        assert torch.equal(keys_all, keys1.view(-1))
+        sharded.local = Indexer(hashing, cg, SIFT.distance, id_base=0, schedule_stats=stats)
     k, P = 10, 6
     qd = [torch.from_numpy(b).to(dev) for b in batches]
     pipe = QueryPipeline(sharded.local, qd[0], k=k, hash_times=P, depth=3, exchange=TopkExchange(k))
     for i, b in enumerate(qd):
         want = single.query_tensors(b, k=k, hash_times=P, seed=70 + i)
-        got = sharded.query_tensors(b, k=k, hash_times=P, seed=70 + i)
+        _, _, ncand, keys64 = sharded.local.query_tensors(b, k=k, hash_times=P, seed=70 + i, want_keys=True)
+        got = gather_and_merge(keys64, ncand, k)
         out = pipe.submit(b, seed=70 + i)
         pipe.synchronize()
         for j in range(3):
