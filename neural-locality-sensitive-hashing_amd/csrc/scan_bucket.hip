@@ -678,6 +678,9 @@ __device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, lo
     constexpr int RPP = NT / KB;             // rows covered by one pass of the workgroup
     [[maybe_unused]] const unsigned long long ts0 = SCAN_NOW();
     [[maybe_unused]] unsigned long long ts_stage = 0, ts_comp = 0;
+#ifdef NLSH_SCAN_TRACE_CLOCK
+    const unsigned long long core0 = __builtin_amdgcn_s_memtime();   // shader-clock counter beside the 100 MHz stamps: the clock held
+#endif
     const int pair0 = __builtin_amdgcn_readfirstlane(desc.x);
     const int nq = __builtin_amdgcn_readfirstlane(desc.y);
     const int row0 = __builtin_amdgcn_readfirstlane(desc.z);
@@ -842,6 +845,9 @@ __device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, lo
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
         o[2] = (float)(((xcc & 0xF) << 12) | (((hw >> 13) & 0x7) << 9) | (((hw >> 12) & 0x1) << 8) | (((hw >> 8) & 0xF) << 4) | (((hw >> 4) & 0x3) << 2));
         o[3] = (float)(hw & 0xF);
+#ifdef NLSH_SCAN_TRACE_CLOCK
+        o[4] = (float)(__builtin_amdgcn_s_memtime() - core0); o[1] = (float)(ts4 - ts0);   // core cycles and 100 MHz ticks of the same interval
+#endif
     }
 #endif
 }

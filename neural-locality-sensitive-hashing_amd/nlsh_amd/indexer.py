@@ -220,7 +220,7 @@ class Indexer:
             est = Q * (1.0 + min(P, 4) * biased / seg)
         return int(min(max(1.5 * est + 1024, Q + 1024), 2 ** 31 - 8))
 
-    def scan_tensors(self, query_vectors, keys, nkeys, k=10, want_keys=False, check=True, events=None):
+    def scan_tensors(self, query_vectors, keys, nkeys, k=10, want_keys=False, check=True, events=None, algo=None):
         """Scan stage on a device key table -> (dist [Q,k], idx [Q,k], ncand [Q], keys64 | None)."""
         if self.metric not in ("l2", "cosine"):
             raise NotImplementedError("fused scan needs metric 'l2' or 'cosine' (use SIFT.distance / Glove.distance)")
@@ -246,7 +246,8 @@ class Indexer:
         pack = torch.empty((Q * k + Q + 2,), dtype=torch.int32, device=dev)
         out_idx, ncand, status = pack[:Q * k].view(Q, k), pack[Q * k:Q * k + Q], pack[Q * k + Q:]
         out_keys = torch.empty((Q, k), dtype=torch.int64, device=dev) if want_keys else None
-        algo = self.choose_algo(Q, P)
+        if algo is None:
+            algo = self.choose_algo(Q, P)
         # the task table is sized per (schedule, batch shape): a larger batch after a smaller one re-estimates instead of
         # reusing a table that `check=False` callers would silently overflow
         tkey = (algo, Q, P)
@@ -369,13 +370,89 @@ class Indexer:
                 return (host[:Q * k].reshape(Q, k), host[Q * k:Q * k + Q], host[n:n + Q * P].reshape(Q, P), host[n + Q * P:n + nk])
             self._grow_task_table(tkey, needed)
 
-    @staticmethod
-    def _plain_lists(idx_h, nc_h):
+    # `query()` on a large batch scans it in `query_chunks` row ranges on the stream and converts range c to Python lists while
+    # the device scans range c+1: the conversion (0.45 ms per 10^4 queries) is as long as the scan, and a single range leaves
+    # the host idle during the scan and the device idle during the conversion.  Results do not depend on the split (the hash
+    # runs once over the whole batch; every query's candidates and top-k are its own; the schedule is the whole batch's).
+    query_chunks = 2
+    _CHUNK_MIN_ROWS = 2048
+
+    def _chunked_results(self, q, keys, nkeys, k, n_chunks):
+        """Generator over row ranges of the batch: (lo, hi, ids [hi-lo, k], counts [hi-lo], keys, nkeys) as host arrays, each
+        yielded as soon as ITS scan and copies are done (one event per range; later ranges keep the device busy meanwhile)."""
+        Q, P = keys.shape
+        dev = q.device
+        algo = self.choose_algo(Q, P)
+        stream = torch.cuda.current_stream(dev)
+        bounds = [(Q * c // n_chunks, Q * (c + 1) // n_chunks) for c in range(n_chunks)]
+        per = max(hi - lo for lo, hi in bounds)
+        words = per * k + per + 2 + per * P + per
+        if self._pin is None or self._pin.numel() < n_chunks * words:
+            self._pin = torch.empty((max(n_chunks * words, 1 << 16),), dtype=torch.int32, pin_memory=True)
+        pin = self._pin
+        inflight = []
+
+        def launch(c, lo, hi):
+            self.scan_tensors(q[lo:hi], keys[lo:hi], nkeys[lo:hi], k=k, check=False, algo=algo)
+            pack, tkey = self._last_pack, self._last_tkey
+            base, n, m = c * words, pack.numel(), hi - lo
+            pin[base:base + n].copy_(pack, non_blocking=True)
+            if self.compat:
+                pin[base + n:base + n + m * P].view(m, P).copy_(keys[lo:hi], non_blocking=True)
+                pin[base + n + m * P:base + n + m * P + m].copy_(nkeys[lo:hi], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            return ev, pack, tkey
+
+        for c, (lo, hi) in enumerate(bounds):
+            inflight.append(launch(c, lo, hi))
+        host = pin.numpy()
+        for c, (lo, hi) in enumerate(bounds):
+            m = hi - lo
+            while True:
+                ev, pack, tkey = inflight[c]
+                ev.synchronize()
+                base, n = c * words, pack.numel()
+                needed, overflow = int(host[base + n - 2]), int(host[base + n - 1])
+                if not overflow or m == 0:
+                    break
+                self._grow_task_table(tkey, needed)                 # task table too small for this range: grow, repeat it
+                inflight[c] = launch(c, lo, hi)
+            a = host[base:base + n + m * P + m]
+            yield (lo, hi, a[:m * k].reshape(m, k), a[m * k:m * k + m], a[n:n + m * P].reshape(m, P), a[n + m * P:n + m * P + m])
+
+    # The fresh result lists (10^4 per batch) land in the collector's youngest generation; the first container allocation after
+    # the conversion then runs a generation-0 collection that walks all of them: 0.25-0.32 ms of a 1.55 ms call on the bench box
+    # (tools/query_host_profile.py, QGC=1).  Instead: (1) a generation-0 collection BEFORE the conversion, while the young
+    # generation holds only what the application made since the last call (microseconds; its cyclic garbage is reclaimed
+    # here, as it would have been); (2) the conversion with the collector paused; (3) gc.freeze() + gc.unfreeze(), which moves
+    # every tracked object to the oldest generation in O(1) and zeroes the young counters, so the results are first walked by
+    # the next FULL collection, like any long-lived object.  Because the counters restart from zero at every call, a tight
+    # query loop would never reach the collector's thresholds for the older generations on its own: every
+    # `_FULL_COLLECT_EVERY`-th promotion is followed by an explicit full collection (tens of ms in a torch process, so rare).
+    # Skipped when the application holds frozen objects of its own (gc.get_freeze_count() > 0), has the collector disabled, or
+    # sets this flag to False.
+    promote_results = True
+    _FULL_COLLECT_EVERY = 2048
+    _promotions = 0
+
+    @classmethod
+    def _plain_lists(cls, idx_h, nc_h):
         """Host arrays -> (list of id rows, list of counts): one C-level conversion each for the whole batch."""
         was_enabled = gc.isenabled()
+        promote = was_enabled and cls.promote_results and len(nc_h) >= 512 and gc.get_freeze_count() == 0
+        if promote:
+            gc.collect(0)
         gc.disable()        # 10^4 fresh lists would trigger a dozen collections over the whole heap: a third of the conversion
         try:
-            return idx_h.tolist(), nc_h.tolist()
+            out = idx_h.tolist(), nc_h.tolist()
+            if promote:
+                gc.freeze()
+                gc.unfreeze()
+                Indexer._promotions += 1
+                if Indexer._promotions % cls._FULL_COLLECT_EVERY == 0:
+                    gc.collect()
+            return out
         finally:
             if was_enabled:
                 gc.enable()
@@ -401,6 +478,17 @@ class Indexer:
             _, idx, ncand, _ = self.scan_tensors(q, keys, nkeys, k=k)
             idx_h, nc_h = idx.cpu().numpy(), ncand.cpu().numpy()
             keys_h, nkeys_h = (keys.cpu().numpy(), nkeys.cpu().numpy()) if self.compat else (None, None)
+        elif self.query_chunks > 1 and q.shape[0] >= self.query_chunks * self._CHUNK_MIN_ROWS:
+            results, counts = [], []
+            for lo, hi, idx_h, nc_h, keys_h, nkeys_h in self._chunked_results(q, keys, nkeys, k, self.query_chunks):
+                key_sets = {}
+                if self.compat:
+                    for qi in np.nonzero(nc_h < k)[0].tolist():
+                        key_sets[qi] = host_key_set(keys_h[qi], int(nkeys_h[qi]), self._hashing.key_mode)
+                r, c = self._to_lists(key_sets, idx_h, nc_h, k)
+                results += r
+                counts += c
+            return results, counts
         else:
             idx_h, nc_h, keys_h, nkeys_h = self._host_results(q, keys, nkeys, k)
         key_sets = {}

@@ -238,3 +238,35 @@ def test_pipeline_survives_dropped_batches_and_weight_updates():
     pipe.synchronize()
     assert torch.equal(out[1], ref[1]) and torch.equal(out[0], ref[0])
     assert not torch.equal(out[1], want[1][1])                        # flipped bits: other buckets, other answers
+
+
+# ----------------------------------------------------------------------------- query() in row ranges (host/device overlap)
+@pytest.mark.parametrize("compat", [True, False])
+def test_query_in_row_ranges_equals_the_single_range_call(compat):
+    """`Indexer.query` scans a large batch in `query_chunks` row ranges and converts one range while the device scans the
+    next; the lists and counts must not depend on the split (including the F7 rule of the short queries and a task-table
+    overflow inside a range)."""
+    from nlsh_amd.data import SIFT
+    from nlsh_amd.indexer import Indexer
+    N, Q, d, H, k, P = 30000, 4500, 128, 12, 10, 10
+    corpus, mean, std = synth.standardise(synth.sift_like(N, d, seed=91))
+    queries = synth.standardise(synth.sift_like(Q, d, seed=92), mean, std)[0]
+    Ws, bs = synth.make_weights([d, 64, H], seed=93)
+    cg, qg = dev(corpus), dev(queries)
+    answers = []
+    for chunks in (1, 2, 3):
+        ix = Indexer(make_hashing(d, [64], H, Ws, bs, compat=compat, seed=5), cg, SIFT.distance, compat=compat)
+        ix.query_chunks, ix._CHUNK_MIN_ROWS = chunks, 1024
+        if chunks == 3:
+            ix._estimate_tasks = lambda *a, **kw: 64          # every range overflows its first task table and is repeated
+        got = [ix.query(qg, k=k, hash_times=P) for _ in range(2)]       # two calls: the call counter seeds the probes
+        answers.append(got)
+        if chunks == 3:
+            assert min(ix._max_tasks.values()) > 64
+    short = sum(1 for n in answers[0][0][1] if n < k)
+    assert short > 0, "the case should hold queries with fewer than k candidates (F7 rule)"
+    for got in answers[1:]:
+        for call in range(2):
+            assert got[call][1] == answers[0][call][1]
+            assert got[call][0] == answers[0][call][0]
+    assert answers[0][0] != answers[0][1]                      # different probe draws per call: the comparison is not vacuous

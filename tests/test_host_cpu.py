@@ -158,3 +158,66 @@ def test_bench_gpus_n_launches_n_ranks_or_fails(tmp_path):
     assert bad.returncode != 0 and "disagrees" in bad.stderr
     one = subprocess.run([sys.executable, bench, "--gpus", "1", "--rehearse-launch"], env=env, capture_output=True, text=True, timeout=120)
     assert one.returncode == 0 and json.loads(one.stdout.splitlines()[-1])["n_gpus"] == 1
+
+
+def test_result_lists_skip_the_young_generation_and_full_collections_still_happen():
+    """`Indexer._plain_lists`: the fresh lists are promoted past the collector's young generations (no collection is
+    triggered by them), the application's own frozen objects are respected, the flag turns it off, and cyclic garbage is
+    still reclaimed by the periodic full collection."""
+    import gc
+    import weakref
+    import numpy as np
+    from nlsh_amd.indexer import Indexer
+    idx, nc = np.arange(20000, dtype=np.int32).reshape(2000, 10), np.full((2000,), 12, dtype=np.int32)
+    seen = []
+    cb = lambda phase, info: seen.append(info["generation"]) if phase == "start" else None   # noqa: E731
+    gc.collect()
+    gc.callbacks.append(cb)
+    try:
+        lists, counts = Indexer._plain_lists(idx, nc)
+        probe = [[i] for i in range(50)]          # container allocations right after: would trip a young collection
+        after, young = list(seen), gc.get_count()[0]
+        assert after == [0] and young < 700 and probe    # only the explicit young pass BEFORE the conversion; none after
+        assert lists == idx.tolist() and counts == nc.tolist()
+        old = Indexer.promote_results
+        Indexer.promote_results = False
+        try:
+            del seen[:]
+            lists2, counts2 = Indexer._plain_lists(idx, nc)     # (the first result stays alive: a freed one hands its count back)
+            probe = [[i] for i in range(50)]
+            after = list(seen)
+            assert after and after[0] == 0 and lists2 == lists
+        finally:
+            Indexer.promote_results = old
+        # an application that froze its own objects keeps them frozen
+        gc.freeze()
+        frozen = gc.get_freeze_count()
+        Indexer._plain_lists(idx, nc)
+        assert gc.get_freeze_count() >= frozen > 0
+        gc.unfreeze()
+        # cyclic garbage made between calls is reclaimed by the periodic full collection
+        class Node:
+            pass
+        a, b = Node(), Node()
+        a.other, b.other = b, a
+        ref = weakref.ref(a)
+        del a, b
+        Indexer._plain_lists(idx, nc)                 # young cyclic garbage goes at the next call (generation-0 pass before it)
+        assert ref() is None
+        # ... and garbage that was promoted before it died is reclaimed by the periodic full collection
+        a, b = Node(), Node()
+        a.other, b.other = b, a
+        ref = weakref.ref(a)
+        Indexer._plain_lists(idx, nc)                 # a and b are alive here: promoted to the oldest generation
+        del a, b
+        Indexer._plain_lists(idx, nc)
+        assert ref() is not None
+        old_every, Indexer._FULL_COLLECT_EVERY = Indexer._FULL_COLLECT_EVERY, 8
+        try:
+            for _ in range(8):
+                Indexer._plain_lists(idx, nc)
+        finally:
+            Indexer._FULL_COLLECT_EVERY = old_every
+        assert ref() is None
+    finally:
+        gc.callbacks.remove(cb)

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--queries", type=int, default=10_000)
     ap.add_argument("--tag", default="")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--tight", type=float, default=0.0, help="task table (= grid of the one-shot scan kernel) set to TIGHT x the tasks the batch needs (experiment; 0: the facade's estimate)")
     args = ap.parse_args()
     Q = args.queries
     if args.workload == "sift1m":
@@ -49,6 +50,8 @@ def main():
     ix = Indexer(hashing, cg, dist_fn, compat=compat, algo=args.algo)
     keys, nkeys = ix.hash_device(qg, hash_times=10, seed=7)
     ix.scan_tensors(qg, keys, nkeys, k=10)                      # sizes the task table
+    if args.tight:
+        ix._max_tasks[ix._last_tkey] = int(args.tight * int(ix.last_status.cpu()[0])) + 1
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.iters)]
     for a, b in evs:
         a.record(); b.record()
@@ -69,7 +72,7 @@ def main():
     dist, idx, nc, _ = out
     rec = {"tag": args.tag, "lib": os.path.basename(os.environ.get("NLSH_HIP_LIB", "default")), "algo": args.algo,
            "scan_kernel_ms": float(kern.mean()), "scan_kernel_ms_min": float(kern.min()), "scan_phases_ms": scan_call_ms,
-           "step_ms": step_ms, "tasks": int(ix.last_status.cpu()[0]), "sum_candidates": int(nc.long().sum())}
+           "step_ms": step_ms, "tasks": int(ix.last_status.cpu()[0]), "max_tasks": ix._max_tasks[ix._last_tkey], "sum_candidates": int(nc.long().sum())}
     if not args.no_check:
         ref = Indexer(hashing, cg, dist_fn, compat=compat, algo="query")
         d0, i0, n0, _ = ref.scan_tensors(qg, keys, nkeys, k=10)
