@@ -194,6 +194,12 @@ def main():
         indexer = Indexer(hashing, shard, distance, compat=H <= 16, seg_rows=args.seg_rows, algo=args.algo)
     torch.cuda.synchronize()
     build_s = time.time() - t0
+    rebuild_s = None
+    if world == 1:      # the build that recurs (the reference rebuilds every 300 training steps, main.py:402): allocator warm
+        t0 = time.time()
+        Indexer(hashing, shard, distance, compat=H <= 16, seg_rows=args.seg_rows, algo=args.algo)
+        torch.cuda.synchronize()
+        rebuild_s = time.time() - t0
     stats = indexer.bucket_stats()
     steps, warmup = args.steps, args.warmup
 
@@ -405,7 +411,7 @@ def main():
                                        f"all-gather of per-shard top-k + merge: {float(np.mean([a.elapsed_time(b) for a, b in ev_x])):.4f} ms/step"
                                        ) if world > 1 else "single GPU",
                        "n_buckets": stats["n_indexes"], "bucket_mean": stats["mean"], "bucket_median": stats["median"],
-                       "bucket_max": stats["max"], "mean_candidates_per_query": mean_c, "index_build_s": build_s,
+                       "bucket_max": stats["max"], "mean_candidates_per_query": mean_c, "index_build_s": build_s, "index_rebuild_s": rebuild_s,
                        "device_step_driver": ("three-stage pipeline over three HIP streams (nlsh_amd/pipeline.py)" if pipe is not None
                                               else "sequential: every kernel of a step back to back on one stream")},
             "roofline": roof,
