@@ -597,12 +597,12 @@ extern "C" int nlsh_encode_hash(const float *x, int64_t n, int64_t x_stride, int
         for (int l = 0; l + 1 < n_layers; ++l) if (a.L[l].Np > max_np) max_np = a.L[l].Np;
         if (72 + round_up(n_probes, 8) > maxKp) a.S = 72 + round_up(n_probes, 8) + 4;
         const size_t lds128 = (size_t)128 * a.S * 4;
-        if (NLSH_ENC_BUILD_128 == 2 && max_np <= 32 * 8) {
-            // two 64-row single-image workgroups per CU (66.5 KB each, 128 VGPRs): one's staging, write-backs and epilogue under the other's MFMAs
-            const size_t lds64 = (size_t)64 * a.S * 4;
-            NLSH_CHECK_HIP(hipFuncSetAttribute((const void *)encode_hash_kernel<2, 8, true, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64));
-            hipLaunchKernelGGL((encode_hash_kernel<2, 8, true, 1, 4>), dim3((unsigned)((n + 63) / 64)), dim3(512), lds64, s, a);
-        } else if (NLSH_ENC_BUILD_128 && max_np <= 32 * 8 && lds128 <= lds_limit) {
+        // r02 also measured two ways of putting a second workgroup on the CU so that one's staging, write-backs and epilogue run
+        // under the other's MFMAs: two 64-row single-image workgroups of eight waves (128 VGPRs, spills outside the k loop): 1.96 ms
+        // per 1M rows; of four waves owning two column tiles each (201 VGPRs): 1.92 ms at an in-kernel clock of 2.23 GHz -- against
+        // 1.895 ms at 2.16 GHz for the form below.  The phases did overlap (tools/enc_trace.py) and the chip gave the gain back as
+        // clock: clock x MFMA duty stayed put.
+        if (NLSH_ENC_BUILD_128 && max_np <= 32 * 8 && lds128 <= lds_limit) {
             // index builds: 128 rows per workgroup on ONE image (accumulators of the four row tiles held in registers across the
             // layer barrier): a B fragment feeds 16 MFMAs instead of 8 and the per-layer fixed cost (write-back, barriers, ring
             // prologue: ~2.5-3.8 us) is paid once per 128 rows instead of once per 64
