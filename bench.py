@@ -225,7 +225,7 @@ def main():
         return indexer.query(qb[i % B], k=k, hash_times=P)
 
     for i in range(max(warmup, 1)):        # at least one: sizes the task table (may retry once); untimed
-        query_lists(-1 - i)
+        ids_api, nc_api = query_lists(-1 - i)   # held like the timed loop holds them: the previous call's lists die when the next arrive
     fence()
     call_s = []
     t0 = time.perf_counter()
@@ -403,6 +403,7 @@ def main():
             "value_protocol": "Indexer.query(batch, k, hash_times) -> Python lists, K synchronous calls (nlsh/trainers/base.py:93-96)" +
                               ("" if world == 1 else f"; sharded: every rank scans all queries over its shard and returns the lists of its 1/{world} slice of the batch"),
             "protocol_median_qps": Q / float(np.median(call_s)),
+            "protocol_call_ms": [round(1e3 * c, 3) for c in call_s],
             "device_resident_qps": Q * steps / elapsed_dev, "device_resident_ms_per_step": 1e3 * elapsed_dev / steps,
             "device_resident_pipelined_qps": piped_qps,
             "config": {"workload": f"{wl['cfg']}, N={N} d={d} Q={Q} H={H} k={k} hash_times={P}, {B} query batches in rotation",
