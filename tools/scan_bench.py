@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--queries", type=int, default=10_000)
     ap.add_argument("--tag", default="")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--zeros", action="store_true", help="zero the grouped corpus and the queries after the index and the keys exist: same tasks and instruction stream, operands that toggle nothing (DVFS probe; pair with -DNLSH_ABLATE=5, ties change the selection)")
     ap.add_argument("--tight", type=float, default=0.0, help="task table (= grid of the one-shot scan kernel) set to TIGHT x the tasks the batch needs (experiment; 0: the facade's estimate)")
     args = ap.parse_args()
     Q = args.queries
@@ -52,6 +53,8 @@ def main():
     ix.scan_tensors(qg, keys, nkeys, k=10)                      # sizes the task table
     if args.tight:
         ix._max_tasks[ix._last_tkey] = int(args.tight * int(ix.last_status.cpu()[0])) + 1
+    if args.zeros:
+        ix.corpus_sorted.zero_(); qg.zero_()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.iters)]
     for a, b in evs:
         a.record(); b.record()
