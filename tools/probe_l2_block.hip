@@ -61,6 +61,29 @@ __global__ __launch_bounds__(256) void k(float *out, unsigned long long *clk, in
                                  : [r0] "v"(r[0]), [r1] "v"(r[1]), [r2] "v"(r[2]), [r3] "v"(r[3]), [q0] "s"(q0), [q1] "s"(q1), [q2] "s"(q2), [q3] "s"(q3), [eps] "s"(eps));
                     acc[i + h] = t0;
                 }
+            } else if (MODE == 7 || MODE == 8) {   // packed f32 (VOP3P): two elements per instruction, two partial sums per accumulator pair
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                f2 qa = {q0, q1}, qb = {q2, q3}, e2 = {eps, eps};
+                f2 ra = {r[0], r[1]}, rb = {r[2], r[3]};
+                f2 a2 = {acc[i], acc[i + 1]};
+                f2 ta, tb;
+                if (MODE == 7) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        asm volatile("v_pk_add_f32 %[ta], %[qa], %[ra] neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %[tb], %[qb], %[rb] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                                     "v_pk_add_f32 %[ta], %[ta], %[e]\n\tv_pk_add_f32 %[tb], %[tb], %[e]\n\t"
+                                     "v_pk_fma_f32 %[a], %[ta], %[ta], %[a]\n\tv_pk_fma_f32 %[a], %[tb], %[tb], %[a]"
+                                     : [a] "+v"(a2), [ta] "=&v"(ta), [tb] "=&v"(tb) : [qa] "s"(qa), [qb] "s"(qb), [ra] "v"(ra), [rb] "v"(rb), [e] "s"(e2));
+                } else {
+                    f2 vqa = {vq0, vq1}, vqb = {vq2, vq3}, ve = {veps, veps};
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        asm volatile("v_pk_add_f32 %[ta], %[qa], %[ra] neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %[tb], %[qb], %[rb] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                                     "v_pk_add_f32 %[ta], %[ta], %[e]\n\tv_pk_add_f32 %[tb], %[tb], %[e]\n\t"
+                                     "v_pk_fma_f32 %[a], %[ta], %[ta], %[a]\n\tv_pk_fma_f32 %[a], %[tb], %[tb], %[a]"
+                                     : [a] "+v"(a2), [ta] "=&v"(ta), [tb] "=&v"(tb) : [qa] "v"(vqa), [qb] "v"(vqb), [ra] "v"(ra), [rb] "v"(rb), [e] "v"(ve));
+                }
+                acc[i] = a2.x; acc[i + 1] = a2.y;
             } else if (MODE == 6) {   // VOP3 fma with SGPR q: t = fma(1.0, q, -c) is not the reference rounding -- rate probe only
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
@@ -107,5 +130,7 @@ int main() {
     run<4>("4 fmac chains only", d, c);
     run<5>("5 sub/add only, SGPR", d, c);
     run<6>("6 fma(-c,1,q) + add + fmac, SGPR", d, c);
+    run<7>("7 packed f32, q/eps SGPR pairs (per VALU-equivalent: 12 per 4 elements)", d, c);
+    run<8>("8 packed f32, q/eps VGPR pairs", d, c);
     return 0;
 }
