@@ -312,8 +312,12 @@ def main():
 
     # candidates per launch of the timed device steps (untimed recomputation with the same batches and probe seeds)
     sum_c = []
+    tables = dict(indexer._max_tasks)          # task tables as the timed steps saw them
     for i in range(steps):
         sum_c.append(int(indexer.query_tensors(qb[i % B], k=k, hash_times=P, seed=1000 + i)[2].long().sum().item()))
+        # every timed step (not only the last, whose status word was read above) fitted its task table
+        needed, tkey = int(indexer.last_status.cpu()[0]), indexer._last_tkey
+        assert tkey not in tables or needed <= tables[tkey], f"step {i}: {needed} tasks > table {tables[tkey]} inside the timed region"
     sum_c_local = float(np.mean(sum_c))
     algo_bytes = 4.0 * d * sum_c_local
     flops_per_pair = 3.0 * d if metric == "l2" else 2.0 * d      # (q-c), +eps, fma per element | one fma
