@@ -885,6 +885,7 @@ __global__ __launch_bounds__(64 * NW, NLSH_TILED_MIN_WAVES) void bscan3_kernel(B
 #pragma unroll
     for (int jq = 0; jq < QW; ++jq) qid_v[jq] = a.task_q[tc * (QW * NW) + NLSH_SLOT(wave, jq)];   // slots >= nq hold garbage, never used
     if (t >= ntasks) return;
+    if (NLSH_ABLATE == 7 && desc.w <= 64) return;   // diagnostic: tasks of <= 64 rows vanish (what a kernel without the tail of tiny tasks would take)
     tiled_task_body<METRIC, QW, NW, TPS>(a, tile, t, desc, qid_v, tid, lane, wave, ts_entry);
 }
 
