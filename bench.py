@@ -353,7 +353,7 @@ def main():
     # HBM traffic / VALU instruction counts per launch: PMC numbers cannot be collected from inside the process; they
     # come from the committed rocprofv3 --pmc passes of this round (taken on the PROFILE box, same workload) when the
     # workload matches, and are labelled as such.
-    traffic, valu_insts, traffic_src = None, None, None
+    traffic, valu_insts, traffic_src, clock_held = None, None, None, None
     try:
         tr = json.load(open(TRAFFIC_FILE))
         w = tr["workload"]
@@ -361,6 +361,7 @@ def main():
                 and args.workload == "sift1m":
             traffic = tr["traffic_bytes_per_launch"].get(str(indexer.last_algo))
             valu_insts = tr.get("valu_wave_instructions_per_launch", {}).get(str(indexer.last_algo))
+            clock_held = tr.get("clock_held_GHz", {}).get(str(indexer.last_algo))
             traffic_src = "profiles/" + os.path.basename(TRAFFIC_FILE) + " (rocprofv3 --pmc on the profile box, same workload; not this run)"
     except (OSError, KeyError, ValueError):
         pass
@@ -395,6 +396,9 @@ def main():
         if valu_insts:
             roof["valu_wave_instructions_per_launch"] = valu_insts
             roof["valu_issue_frac"] = valu_insts * 2.0 / (1024 * t_scan * 2.4e9)
+            if clock_held:   # the chip holds less than 2.4 GHz in this kernel: the same fraction at that clock
+                roof["clock_held_GHz"] = clock_held
+                roof["valu_issue_frac_at_clock_held"] = valu_insts * 2.0 / (1024 * t_scan * clock_held * 1e9)
         if copy_gbps is not None:
             roof["hbm_copy_measured_GBps"] = copy_gbps
         result = {
@@ -410,6 +414,9 @@ def main():
             "protocol_call_ms": [round(1e3 * c, 3) for c in call_s],
             "device_resident_qps": Q * steps / elapsed_dev, "device_resident_ms_per_step": 1e3 * elapsed_dev / steps,
             "device_resident_pipelined_qps": piped_qps,
+            # the five quantities the reference's validation logs (nlsh/trainers/base.py:87-90,105-108), same names
+            "test_metrics": {"test/n_indexes": stats["n_indexes"], "test/std_index_rows": stats["std_index_rows"], "test/recall": recall,
+                             "test/query_size": mean_c, "test/qps": Q * steps / elapsed},
             "config": {"workload": f"{wl['cfg']}, N={N} d={d} Q={Q} H={H} k={k} hash_times={P}, {B} query batches in rotation",
                        "hash": hash_desc,
                        "parallelism": (f"corpus {args.shard} sharded x{world} ({indexer._candidate_vectors_gpu.shape[0]} rows on rank 0), "
