@@ -74,6 +74,7 @@ def parse(argv=None):
     ap.add_argument("--seg-rows", type=int, default=0)
     ap.add_argument("--shard", default="buckets", choices=["buckets", "rows"],
                     help="N>1 partition of the corpus: whole buckets per rank (default) or contiguous row ranges")
+    ap.add_argument("--query-chunks", type=int, default=None, help="row ranges Indexer.query() scans a batch in (default: the facade's, 2); 1 for profiling runs: every scan launch of the process then has the full-batch grid and per-kernel-NAME statistics mean one thing")
     ap.add_argument("--pipeline", default="auto", choices=["auto", "on", "off"],
                     help="device-resident region only.  on: three-stage pipeline over three HIP streams; off: every kernel of a "
                          "step back to back on one stream (each kernel alone on the chip); auto: on for N>1, off for N=1")
@@ -200,6 +201,8 @@ def main():
         Indexer(hashing, shard, distance, compat=H <= 16, seg_rows=args.seg_rows, algo=args.algo)
         torch.cuda.synchronize()
         rebuild_s = time.time() - t0
+    if args.query_chunks is not None:
+        Indexer.query_chunks = max(1, args.query_chunks)
     stats = indexer.bucket_stats()
     steps, warmup = args.steps, args.warmup
 
