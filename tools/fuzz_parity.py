@@ -25,6 +25,9 @@ from nlsh_amd.indexer import Indexer  # noqa: E402
 from oracle import oracle  # noqa: E402
 
 
+from nlsh_amd.hashings import host_key_set  # noqa: E402
+
+
 def one_case(rng, case_id):
     metric = rng.choice(["l2", "cosine"])
     d = int(rng.choice([8, 25, 50, 64, 96, 100, 128, 200, 300, 512, 960, 1024]))
@@ -68,6 +71,26 @@ def one_case(rng, case_id):
         rows = np.concatenate(rows) if rows else np.zeros(0, np.int32)
         _, d64 = oracle.distances(queries[q], corpus, rows, metric, f64=True)
         check_topk_against_candidates(idx[q], dist[q], rows, d64, k)
+    # the reference-typed call on the same keys, scanned in 1-3 row ranges: its lists are the tensor rows (queries with >= k
+    # candidates) / every candidate (fewer, compat off) / the last key's bucket (fewer, compat on: F7)
+    twin = make_hashing(d, hidden, H, Ws, bs, compat=compat)
+    twin.next_seed()                                                # the index build drew one seed from the hasher's call counter
+    seed = twin.next_seed()                                         # what indexer.query() will draw next
+    keys2, nkeys2 = indexer.hash_device(qd, hash_times=P, seed=seed)
+    d2, i2, n2, _ = indexer.scan_tensors(qd, keys2, nkeys2, k=k)
+    indexer.query_chunks, indexer._CHUNK_MIN_ROWS = int(rng.integers(1, 4)), 16
+    lists, counts = indexer.query(qd, k=k, hash_times=P)
+    i2, n2 = i2.cpu().numpy(), n2.cpu().numpy()
+    assert counts == n2.tolist(), desc
+    k2h, nk2h = keys2.cpu().numpy(), nkeys2.cpu().numpy()
+    for q in range(Q):
+        if n2[q] >= k:
+            assert lists[q] == i2[q].tolist(), (desc, q)
+        elif not compat:
+            assert lists[q] == [int(v) for v in i2[q] if v >= 0], (desc, q)
+        else:
+            ks = list(host_key_set(k2h[q], int(nk2h[q]), indexer._hashing.key_mode))
+            assert lists[q] == (indexer._rows_of_key(ks[-1]) if ks else []), (desc, q)
     exact = int((idx == oi).all(1).sum())
     assert exact >= 0.9 * Q - 2, (desc, exact)      # fp32 near-ties may resolve either way; the checks above bound them
     return desc, exact / Q
