@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--tag", default="")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--zeros", action="store_true", help="zero the grouped corpus and the queries after the index and the keys exist: same tasks and instruction stream, operands that toggle nothing (DVFS probe; pair with -DNLSH_ABLATE=5, ties change the selection)")
+    ap.add_argument("--order", default="", choices=["", "pairs", "work", "density"], help="experiment: schedule order of the buckets recomputed on the host from THIS batch's keys (pairs: by (query, probe) pairs hitting the bucket; work: pairs x rows; density: full 16-query groups first, then by pairs), in place of the static size order")
     ap.add_argument("--tight", type=float, default=0.0, help="task table (= grid of the one-shot scan kernel) set to TIGHT x the tasks the batch needs (experiment; 0: the facade's estimate)")
     args = ap.parse_args()
     Q = args.queries
@@ -50,6 +51,19 @@ def main():
     cg, qg = torch.from_numpy(corpus_h).cuda(), torch.from_numpy(queries_h).cuda()
     ix = Indexer(hashing, cg, dist_fn, compat=compat, algo=args.algo)
     keys, nkeys = ix.hash_device(qg, hash_times=10, seed=7)
+    if args.order:
+        uk = ix.uniq_keys.cpu().numpy().astype(np.int64)
+        kh, nh = keys.cpu().numpy().astype(np.int64), nkeys.cpu().numpy()
+        valid = np.arange(kh.shape[1])[None, :] < nh[:, None]
+        flat = kh[valid]
+        pos = np.searchsorted(uk, flat)
+        pos[pos >= len(uk)] = 0
+        hit = uk[pos] == flat
+        m = np.bincount(pos[hit], minlength=len(uk)).astype(np.int64)
+        size = ix.bucket_sizes.astype(np.int64)
+        key = {"pairs": m * 100000 + size, "work": m * size, "density": np.minimum(m, 16) * 10**9 + m * 4096 + size}[args.order]
+        order = np.argsort(-key, kind="stable").astype(np.int32)
+        ix.bucket_order = torch.from_numpy(order).cuda()
     ix.scan_tensors(qg, keys, nkeys, k=10)                      # sizes the task table
     if args.tight:
         ix._max_tasks[ix._last_tkey] = int(args.tight * int(ix.last_status.cpu()[0])) + 1
