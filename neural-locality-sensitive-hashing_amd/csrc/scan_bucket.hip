@@ -615,13 +615,16 @@ __device__ __forceinline__ void l2_task(float4 *tile, const float4 *corpus4, lon
     const int nkb = (d4 + KBt - 1) / KBt;
     const int sc = tid & (KBt - 1), sr = tid / KBt;   // staging map: KBt threads cover 16*KBt contiguous bytes of a row
     float4 stg[SPT];
-    auto stage_load = [&](int kb) {
-        const int gc = kb * KBt + sc;
+    // Rows past the end of the segment and chunks past the end of a row are CLAMPED, not zero-filled: the clamped loads read valid
+    // memory, rows >= nrows are masked at the epilogue (`valid`) and a k-block only evaluates its `nchunk` real chunks.  Guarded,
+    // every staged word sat behind its own exec mask + branch + zero fill: ~22 VALU, 12 SALU and 4 branches per stage and wave.
+    const float4 *rowp[SPT];
 #pragma unroll
-        for (int i = 0; i < SPT; ++i) {
-            const int r = sr + RPPt * i;
-            stg[i] = (NLSH_ABLATE != 2 && r < nrows && gc < d4) ? corpus4[(long long)(row0 + r) * stride4 + gc] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    for (int i = 0; i < SPT; ++i) rowp[i] = corpus4 + (long long)(row0 + min(sr + RPPt * i, nrows - 1)) * stride4;
+    auto stage_load = [&](int kb) {
+        const int gc = min(kb * KBt + sc, d4 - 1);
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) stg[i] = NLSH_ABLATE != 2 ? rowp[i][gc] : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     stage_load(0);
     for (int kb = 0; kb < nkb; ++kb) {
@@ -714,13 +717,16 @@ __device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, lo
     // staging map: KBt threads cover 16*KBt contiguous bytes of a row
     const int sc = tid & (KBt - 1), sr = tid / KBt;
     float4 stg[SPT];
-    auto stage_load = [&](int kb) {
-        const int gc = kb * KBt + sc;
+    // Rows past the end of the segment and chunks past the end of a row are CLAMPED, not zero-filled: the clamped loads read valid
+    // memory, rows >= nrows are masked at the epilogue (`valid`) and a k-block only evaluates its `nchunk` real chunks.  Guarded,
+    // every staged word sat behind its own exec mask + branch + zero fill: ~22 VALU, 12 SALU and 4 branches per stage and wave.
+    const float4 *rowp[SPT];
 #pragma unroll
-        for (int i = 0; i < SPT; ++i) {
-            const int r = sr + RPPt * i;
-            stg[i] = (NLSH_ABLATE != 2 && r < nrows && gc < d4) ? corpus4[(long long)(row0 + r) * stride4 + gc] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    for (int i = 0; i < SPT; ++i) rowp[i] = corpus4 + (long long)(row0 + min(sr + RPPt * i, nrows - 1)) * stride4;
+    auto stage_load = [&](int kb) {
+        const int gc = min(kb * KBt + sc, d4 - 1);
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) stg[i] = NLSH_ABLATE != 2 ? rowp[i][gc] : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     float acc[TPS][QW];
 #pragma unroll
