@@ -90,6 +90,18 @@ def main():
     rec = {"tag": args.tag, "lib": os.path.basename(os.environ.get("NLSH_HIP_LIB", "default")), "algo": args.algo,
            "scan_kernel_ms": float(kern.mean()), "scan_kernel_ms_min": float(kern.min()), "scan_phases_ms": scan_call_ms,
            "step_ms": step_ms, "tasks": int(ix.last_status.cpu()[0]), "max_tasks": ix._max_tasks[ix._last_tkey], "sum_candidates": int(nc.long().sum())}
+    if os.environ.get("SCAN_BENCH_GROUPS"):   # pairs by the size of the query group they sit in (host recomputation from the keys)
+        uk = ix.uniq_keys.cpu().numpy().astype(np.int64)
+        kh, nh = keys.cpu().numpy().astype(np.int64), nkeys.cpu().numpy()
+        flat = kh[np.arange(kh.shape[1])[None, :] < nh[:, None]]
+        pos = np.searchsorted(uk, flat); pos[pos >= len(uk)] = 0
+        m = np.bincount(pos[uk[pos] == flat], minlength=len(uk)).astype(np.int64)
+        size = ix.bucket_sizes.astype(np.int64)
+        rem = m % 16
+        tot = float((m * size).sum())
+        rec["pairs_share_by_group_size"] = {"16": float(((m - rem) * size).sum()) / tot, **{f"<={n}": float((rem * size)[(rem > 0) & (rem <= n)].sum()) / tot for n in (4, 8, 12, 15)}}
+        segs = (size + 255) // 256
+        rec["tasks_by_group_size"] = {"16": int(((m // 16) * segs).sum()), **{f"<={n}": int(segs[(rem > 0) & (rem <= n)].sum()) for n in (4, 8, 12, 15)}}
     if not args.no_check:
         ref = Indexer(hashing, cg, dist_fn, compat=compat, algo="query")
         d0, i0, n0, _ = ref.scan_tensors(qg, keys, nkeys, k=10)
