@@ -837,6 +837,22 @@ __device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, lo
                 key[tl] = kk < tau_g ? kk : KEY_NONE;  // beyond another list's k-th best: cannot reach the final top-k
             }
             uint64_t *out = a.partial + ((long long)t * (QW * NW) + NLSH_SLOT(wave, jq)) * a.k;
+#ifdef NLSH_SCAN_TRACE_EPILOGUE
+            {   // diagnostic: how many (task, query) lists reach the selection with a published bound, and with how many survivors
+                int n_all = 0, n_live = 0;
+#pragma unroll
+                for (int tl = 0; tl < TPS; ++tl) { n_all += __popcll(__ballot(valid[tl])); n_live += __popcll(__ballot(key[tl] != KEY_NONE)); }
+                if (lane == 0) {
+                    float *c = g_scan_trace + (NLSH_TRACE_SLOTS - 1) * 8;
+                    atomicAdd(c + 0, 1.0f);
+                    if (tau_g != KEY_NONE) atomicAdd(c + 1, 1.0f);
+                    if (n_live == 0) atomicAdd(c + 2, 1.0f);
+                    else if (n_live < a.k) atomicAdd(c + 3, 1.0f);
+                    atomicAdd(c + 4, (float)n_all);
+                    atomicAdd(c + 5, (float)n_live);
+                }
+            }
+#endif
             if (NLSH_ABLATE != 3) {
                 const uint64_t bound = select_k_smallest<TPS>(key, a.k, lane, out);
                 if (bound != KEY_NONE && lane == 0) atomicMin(a.tauq + qid[jq], (unsigned long long)bound);
