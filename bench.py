@@ -375,7 +375,12 @@ def main():
         gt = brute_force_topk(qb[0], corpus_d, k, metric).cpu().numpy()
         del corpus_d
     own = False                      # untimed: all lists on every rank (rank 0 computes the recall from them)
-    ids0, nc0 = query_lists(0)       # every rank takes part in the (collective) protocol call the recall is computed from
+    # every rank takes part in the (collective) protocol call the recall is computed from; ONE fixed probe seed at every N,
+    # so recall@10 and the candidate counts are the same numbers at 1, 2, 4 and 8 GPUs
+    if sharded is not None:
+        ids0, nc0 = sharded.query(qb[0], k=k, hash_times=P, seed=5000, own_slice=False)
+    else:
+        ids0, nc0 = indexer.query(qb[0], k=k, hash_times=P, seed=5000)
     if rank == 0:
         recall = float(np.mean(calculate_recall(list(gt), ids0)))
         mean_c = float(np.mean(nc0))

@@ -469,11 +469,13 @@ class Indexer:
                 results[qi] = [int(v) for v in idx_h[qi] if v >= 0]
         return results, counts
 
-    def query(self, query_vectors, k=10, hash_times=10) -> Tuple[List[List[int]], List[int]]:
+    def query(self, query_vectors, k=10, hash_times=10, seed=None) -> Tuple[List[List[int]], List[int]]:
+        """nlsh/indexer.py:56-96.  `seed` (not in the reference): the Philox seed of the multi-probe draws; None takes the next one
+        from the hasher's call counter, like every other hashing call."""
         if self.metric not in ("l2", "cosine"):
             return self._query_generic(query_vectors, k, hash_times)
         q = self._as_queries(query_vectors)
-        keys, nkeys = self.hash_device(q, hash_times=hash_times)
+        keys, nkeys = self.hash_device(q, hash_times=hash_times, seed=seed)
         if keys.shape[1] > _capi.MAX_PROBES:
             _, idx, ncand, _ = self.scan_tensors(q, keys, nkeys, k=k)
             idx_h, nc_h = idx.cpu().numpy(), ncand.cpu().numpy()

@@ -125,6 +125,12 @@ def test_bench_gpus_2_self_launch_reports_two_ranks():
     assert rec["scaling"] == "strong" and 0 <= rec["recall_at_10"] <= 1
     assert rec["roofline"]["frac"] <= 1.0 and rec["roofline"]["bound"] in ("valu", "hbm")
     assert "sharded x2" in rec["config"]["parallelism"]
+    # recall and candidate counts are the same numbers at every GPU count (one fixed probe seed for the recall call)
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + cmd[4:], env=env, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    rec1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec1["n_gpus"] == 1 and rec1["recall_at_10"] == rec["recall_at_10"]
+    assert rec1["config"]["mean_candidates_per_query"] == rec["config"]["mean_candidates_per_query"]
 
 
 def _rccl_worker(rank, port, shard, out_dir):
