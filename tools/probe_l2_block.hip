@@ -84,6 +84,21 @@ __global__ __launch_bounds__(256) void k(float *out, unsigned long long *clk, in
                                      : [a] "+v"(a2), [ta] "=&v"(ta), [tb] "=&v"(tb) : [qa] "v"(vqa), [qb] "v"(vqb), [ra] "v"(ra), [rb] "v"(rb), [e] "v"(ve));
                 }
                 acc[i] = a2.x; acc[i + 1] = a2.y;
+            } else if (MODE == 9) {   // packed sub and add (same roundings per element), scalar fmac chain in k order: bit-identical to mode 2
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                f2 qa = {q0, q1}, qb = {q2, q3}, e2 = {eps, eps};
+                f2 ra = {r[0], r[1]}, rb = {r[2], r[3]};
+                f2 ta, tb;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                {
+                    asm volatile("v_pk_add_f32 %[ta], %[qa], %[ra] neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %[tb], %[qb], %[rb] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                                 "v_pk_add_f32 %[ta], %[ta], %[e]\n\tv_pk_add_f32 %[tb], %[tb], %[e]"
+                                 : [ta] "=&v"(ta), [tb] "=&v"(tb) : [qa] "s"(qa), [qb] "s"(qb), [ra] "v"(ra), [rb] "v"(rb), [e] "s"(e2));
+                    const float t0 = ta.x, t1 = ta.y, t2 = tb.x, t3 = tb.y;   // sub-registers of the pairs: no copies
+                    asm volatile("v_fmac_f32 %[a], %[t0], %[t0]\n\tv_fmac_f32 %[a], %[t1], %[t1]\n\tv_fmac_f32 %[a], %[t2], %[t2]\n\tv_fmac_f32 %[a], %[t3], %[t3]"
+                                 : [a] "+v"(acc[i + h]) : [t0] "v"(t0), [t1] "v"(t1), [t2] "v"(t2), [t3] "v"(t3));
+                }
             } else if (MODE == 6) {   // VOP3 fma with SGPR q: t = fma(1.0, q, -c) is not the reference rounding -- rate probe only
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
@@ -132,5 +147,6 @@ int main() {
     run<6>("6 fma(-c,1,q) + add + fmac, SGPR", d, c);
     run<7>("7 packed f32, q/eps SGPR pairs (per VALU-equivalent: 12 per 4 elements)", d, c);
     run<8>("8 packed f32, q/eps VGPR pairs", d, c);
+    run<9>("9 packed sub+add, scalar fmac chain (bit-identical to 2)", d, c);
     return 0;
 }
