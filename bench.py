@@ -42,6 +42,9 @@ import subprocess
 import sys
 import time
 
+# multi-process GPU work on this pool needs dmabuf IPC (the image exports it already; a bare launcher environment may not)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "neural-locality-sensitive-hashing_amd")):
     if p not in sys.path:
