@@ -45,6 +45,13 @@ extern "C" int nlsh_debug_scan_trace(float *host, int n_floats) {
 #ifndef NLSH_ABLATE_NQ
 #define NLSH_ABLATE_NQ 4
 #endif
+// Instruction-arbitration priority of a wave outside / inside the distance loop (s_setprio, 0..3; -1: leave it alone).
+#ifndef NLSH_PRIO_OUT
+#define NLSH_PRIO_OUT -1
+#endif
+#ifndef NLSH_PRIO_MATH
+#define NLSH_PRIO_MATH -1
+#endif
 #ifndef NLSH_FAT_STAGES
 #define NLSH_FAT_STAGES 1
 #endif
@@ -646,7 +653,9 @@ __device__ __forceinline__ void l2_task(float4 *tile, const float4 *corpus4, lon
             const_f32p qk[4];
 #pragma unroll
             for (int jq = 0; jq < 4; ++jq) qk[jq] = qs[jq] + kb * KBt * 4;
+            if (NLSH_PRIO_MATH >= 0) __builtin_amdgcn_s_setprio(NLSH_PRIO_MATH);
             l2_kblock<(NQ > 0 ? NQ : 1), NTL>(tile + lane * RSt, RSt, nchunk, qk, acc);
+            if (NLSH_PRIO_OUT >= 0) __builtin_amdgcn_s_setprio(NLSH_PRIO_OUT);
 #ifdef NLSH_SCAN_TRACE
             asm volatile("" : "+v"(acc[0][0]));
             tr[2] += SCAN_NOW() - tc;
@@ -889,6 +898,7 @@ __global__ __launch_bounds__(64 * NW, NLSH_TILED_MIN_WAVES) void bscan3_kernel(B
     __shared__ float4 tile[ROWS * RS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     [[maybe_unused]] const unsigned long long ts_entry = SCAN_NOW();
+    if (NLSH_PRIO_OUT >= 0) __builtin_amdgcn_s_setprio(NLSH_PRIO_OUT);
     long long ntasks = a.status[0];
     if (ntasks > a.max_tasks) {
         if (blockIdx.x == 0 && threadIdx.x == 0) a.status[1] = 1;  // incomplete: caller must retry
