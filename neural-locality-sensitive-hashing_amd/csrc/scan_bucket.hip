@@ -52,6 +52,9 @@ extern "C" int nlsh_debug_scan_trace(float *host, int n_floats) {
 #ifndef NLSH_PRIO_MATH
 #define NLSH_PRIO_MATH -1
 #endif
+#ifndef NLSH_WARM_QLINES
+#define NLSH_WARM_QLINES 1
+#endif
 #ifndef NLSH_FAT_STAGES
 #define NLSH_FAT_STAGES 1
 #endif
@@ -610,6 +613,30 @@ __device__ __forceinline__ void l2_kblock(const float4 *col, int RSt, int nchunk
     }
 }
 
+// Scalar-cache warm-up of the query lines a k-block will read.  Every 64-byte line of a query is read by exactly one wave exactly once
+// per task, so its first `s_load` always misses the scalar cache (SQC_DCACHE: 5.2 M requests, 1.08 M misses per launch = one per line) and
+// the k-block's first wait -- directly behind the load -- sat through an L2 round trip eight times per task.  A throw-away one-dword load
+// of each line, issued a stage earlier (the result register is never read), moves that round trip under the barriers and the LDS
+// write of the stage in between.  gfx950 has no scalar prefetch instruction.
+// `sink` is the destination of every throw-away load and MUST stay allocated until a `s_waitcnt lgkmcnt(0)` behind them (the loads
+// complete asynchronously: a destination the compiler has already handed to another value is overwritten when they land -- the first
+// version of this did exactly that and faulted).  It is threaded through the statements as a read-write operand and released by
+// `warm_query_lines_done` after the wait.
+template <int NQ>
+__device__ __forceinline__ void warm_query_lines(const const_f32p (&qs)[4], int byte_off, int byte_end, float &sink) {
+#if NLSH_WARM_QLINES
+    for (int off = byte_off; off < byte_end; off += 64) {
+#pragma unroll
+        for (int jq = 0; jq < NQ; ++jq) asm volatile("s_load_dword %0, %1, %2" : "+s"(sink) : "s"(qs[jq]), "s"(off));
+    }
+#endif
+}
+__device__ __forceinline__ void warm_query_lines_done(float &sink) {
+#if NLSH_WARM_QLINES
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sink)::"memory");
+#endif
+}
+
 // All k-blocks of one L2 task for a wave that holds NQ (0..4) of its queries, NTL = tiles of the task (1..4): staging
 // (global -> registers -> LDS, next k-block's loads in flight during the current one) + the hand-scheduled k-blocks.
 // The (NQ, NTL) pair is chosen ONCE per task, outside the k-block loop: chosen per k-block, the 16 accumulators crossed
@@ -637,6 +664,9 @@ __device__ __forceinline__ void l2_task(float4 *tile, const float4 *corpus4, lon
         for (int i = 0; i < SPT; ++i) stg[i] = NLSH_ABLATE != 2 ? rowp[i][gc] : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     stage_load(0);
+    float qsink = 0.0f;
+    asm volatile("" : "+s"(qsink));
+    if (NQ > 0) warm_query_lines<(NQ > 0 ? NQ : 1)>(qs, 0, min(KBt, d4) * 16, qsink);
     for (int kb = 0; kb < nkb; ++kb) {
         [[maybe_unused]] const unsigned long long ta = SCAN_NOW();
         __syncthreads();  // everyone has finished reading the previous k-block
@@ -648,6 +678,7 @@ __device__ __forceinline__ void l2_task(float4 *tile, const float4 *corpus4, lon
         [[maybe_unused]] const unsigned long long tc = SCAN_NOW();
         tr[0] += tb - ta;   // first barrier: the slowest wave's previous k-block
         tr[1] += tc - tb;   // own stage data (vmcnt) + LDS write + second barrier
+        if (NQ > 0) warm_query_lines_done(qsink);   // behind the two barriers: the lines of this k-block are in the scalar cache
         if (NQ > 0 && NLSH_ABLATE != 1 && NLSH_ABLATE != 6) {
             const int nchunk = min(KBt, d4 - kb * KBt);
             const_f32p qk[4];
@@ -656,6 +687,7 @@ __device__ __forceinline__ void l2_task(float4 *tile, const float4 *corpus4, lon
             if (NLSH_PRIO_MATH >= 0) __builtin_amdgcn_s_setprio(NLSH_PRIO_MATH);
             l2_kblock<(NQ > 0 ? NQ : 1), NTL>(tile + lane * RSt, RSt, nchunk, qk, acc);
             if (NLSH_PRIO_OUT >= 0) __builtin_amdgcn_s_setprio(NLSH_PRIO_OUT);
+            if (kb + 1 < nkb) warm_query_lines<(NQ > 0 ? NQ : 1)>(qs, (kb + 1) * KBt * 16, min((kb + 2) * KBt, d4) * 16, qsink);
 #ifdef NLSH_SCAN_TRACE
             asm volatile("" : "+v"(acc[0][0]));
             tr[2] += SCAN_NOW() - tc;
