@@ -952,6 +952,7 @@ __global__ __launch_bounds__(64 * NW, NLSH_TILED_MIN_WAVES) void bscan3_kernel(B
 #pragma unroll
     for (int jq = 0; jq < QW; ++jq) qid_v[jq] = a.task_q[tc * (QW * NW) + NLSH_SLOT(wave, jq)];   // slots >= nq hold garbage, never used
     if (t >= ntasks) return;
+    if (NLSH_ABLATE == 9) return;   // diagnostic: every workgroup leaves after its descriptor loads (what dispatching the grid costs)
     if (NLSH_ABLATE == 8 && desc.y <= NLSH_ABLATE_NQ) return;   // diagnostic: tasks with few queries vanish (what the low-density tasks cost)
     if (NLSH_ABLATE == 7 && desc.w <= 64) return;   // diagnostic: tasks of <= 64 rows vanish (what a kernel without the tail of tiny tasks would take)
     tiled_task_body<METRIC, QW, NW, TPS>(a, tile, t, desc, qid_v, tid, lane, wave, ts_entry);
