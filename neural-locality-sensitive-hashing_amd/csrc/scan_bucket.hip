@@ -55,6 +55,9 @@ extern "C" int nlsh_debug_scan_trace(float *host, int n_floats) {
 #ifndef NLSH_WARM_QLINES
 #define NLSH_WARM_QLINES 1
 #endif
+#ifndef NLSH_FAST_COSINE
+#define NLSH_FAST_COSINE 1   // cosine tasks through the hand-scheduled k-blocks too (0: the compiler-scheduled generic loop)
+#endif
 #ifndef NLSH_FAT_STAGES
 #define NLSH_FAT_STAGES 1
 #endif
@@ -564,6 +567,38 @@ __device__ __forceinline__ void l2_tile_block(float (&acc)[4], const float4 r, c
 #undef NLSH_QBLK
 #undef NLSH_QIN
 #undef NLSH_TMP
+
+// Cosine form of the block: acc += q_k * c_k in ascending k (the same fmaf chain as apply_qchunk), one VALU per element.  The
+// query chunk is read from VGPR COPIES made once per chunk (`QCopy`, 4 v_mov per query) and used by all NT tile blocks of the chunk:
+// a v_fmac that reads its multiplier from an SGPR issues at about half the rate of one that reads a VGPR (tools/probe_l2_block.hip),
+// and here EVERY instruction would read one.
+struct QCopy { float4 v[4]; };
+#define NLSH_CBLK(J)                                                                                              \
+    "v_fmac_f32 %[a" #J "], %[q" #J "0], %[r0]\n\tv_fmac_f32 %[a" #J "], %[q" #J "1], %[r1]\n\t"                     \
+    "v_fmac_f32 %[a" #J "], %[q" #J "2], %[r2]\n\tv_fmac_f32 %[a" #J "], %[q" #J "3], %[r3]\n\t"
+#define NLSH_CIN(J) [q##J##0] "v"(q.v[J].x), [q##J##1] "v"(q.v[J].y), [q##J##2] "v"(q.v[J].z), [q##J##3] "v"(q.v[J].w)
+template <int NQ>
+__device__ __forceinline__ void cos_tile_block(float (&acc)[4], const float4 r, const QCopy &q) {
+    if (NQ == 4)
+        asm volatile(NLSH_CBLK(0) NLSH_CBLK(1) NLSH_CBLK(2) NLSH_CBLK(3)
+                     : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3])
+                     : NLSH_RIN, NLSH_CIN(0), NLSH_CIN(1), NLSH_CIN(2), NLSH_CIN(3));
+    else if (NQ == 3)
+        asm volatile(NLSH_CBLK(0) NLSH_CBLK(1) NLSH_CBLK(2)
+                     : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2])
+                     : NLSH_RIN, NLSH_CIN(0), NLSH_CIN(1), NLSH_CIN(2));
+    else if (NQ == 2)
+        asm volatile(NLSH_CBLK(0) NLSH_CBLK(1) : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]) : NLSH_RIN, NLSH_CIN(0), NLSH_CIN(1));
+    else
+        asm volatile(NLSH_CBLK(0) : [a0] "+v"(acc[0]) : NLSH_RIN, NLSH_CIN(0));
+}
+template <int NQ>
+__device__ __forceinline__ void copy_qset(QCopy &dst, const QSet &src) {
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) dst.v[j] = make_float4(src.v[j].x, src.v[j].y, src.v[j].z, src.v[j].w);
+}
+#undef NLSH_CBLK
+#undef NLSH_CIN
 #undef NLSH_RIN
 
 // One k-block (nchunk 16-byte chunks of every row, LDS row stride RSt slots) for a wave that holds NQ queries, on NT
@@ -574,9 +609,11 @@ __device__ __forceinline__ void l2_tile_block(float (&acc)[4], const float4 r, c
 // last chunk (valid addresses, values unused) instead of being guarded -- guarded, the loop carried 8 branches, 22
 // scalar-ALU instructions and 25 s_nops per 384 VALU, and on this machine instruction issue is what the kernel is
 // bound by (r02: kernel time tracks VALU x 2.3 + scalar x 2..4 cycles per SIMD across every variant measured).
-template <int NQ, int NT>
+template <int NQ, int NT, int METRIC = NLSH_METRIC_L2_EPS>
 __device__ __forceinline__ void l2_kblock(const float4 *col, int RSt, int nchunk, const const_f32p (&qk)[4], float (&acc)[4][4]) {
+    constexpr bool COS = METRIC == NLSH_METRIC_COSINE;
     QSet qa, qb;
+    [[maybe_unused]] QCopy qv;   // cosine: VGPR copies of the current chunk's queries
     float4 rr[2];
     const int TS = 64 * RSt;   // tile stride in float4 slots
     const int last = nchunk - 1;
@@ -597,7 +634,12 @@ __device__ __forceinline__ void l2_kblock(const float4 *col, int RSt, int nchunk
                 else load_qset<NQ>(qa, qk, 16 * c2, rr[j & 1].x);
             }
             __builtin_amdgcn_sched_barrier(0);
-            l2_tile_block<NQ>(acc[tl], rr[j & 1], cc ? qb : qa);
+            if (COS) {
+                if (tl == 0) copy_qset<NQ>(qv, cc ? qb : qa);   // this chunk's set was waited for behind the previous chunk's last block
+                cos_tile_block<NQ>(acc[tl], rr[j & 1], qv);
+            } else {
+                l2_tile_block<NQ>(acc[tl], rr[j & 1], cc ? qb : qa);
+            }
             if (tl == NT - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the next chunk's queries (and first row chunk)
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -607,7 +649,12 @@ __device__ __forceinline__ void l2_kblock(const float4 *col, int RSt, int nchunk
         for (int j = 0; j < NT; ++j) {
             if (j + 1 < NT) rr[(j + 1) & 1] = col[(j + 1) * TS + c];
             __builtin_amdgcn_sched_barrier(0);
-            l2_tile_block<NQ>(acc[j], rr[j & 1], qa);
+            if (COS) {
+                if (j == 0) copy_qset<NQ>(qv, qa);
+                cos_tile_block<NQ>(acc[j], rr[j & 1], qv);
+            } else {
+                l2_tile_block<NQ>(acc[j], rr[j & 1], qa);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -642,7 +689,7 @@ __device__ __forceinline__ void warm_query_lines_done(float &sink) {
 // The (NQ, NTL) pair is chosen ONCE per task, outside the k-block loop: chosen per k-block, the 16 accumulators crossed
 // a 16-way switch every k-block and the register allocator copied all of them in and out each time (466 v_mov in the
 // kernel, +67 % instructions on small shapes).  NTL also fixes the fat-stage geometry at compile time.
-template <int NW, int NQ, int NTL>
+template <int NW, int NQ, int NTL, int METRIC = NLSH_METRIC_L2_EPS>
 __device__ __forceinline__ void l2_task(float4 *tile, const float4 *corpus4, long long stride4, int d4, int row0, int nrows,
                                         const const_f32p (&qs)[4], int tid, int lane, float (&acc)[4][4],
                                         [[maybe_unused]] unsigned long long (&tr)[3]) {
@@ -685,7 +732,7 @@ __device__ __forceinline__ void l2_task(float4 *tile, const float4 *corpus4, lon
 #pragma unroll
             for (int jq = 0; jq < 4; ++jq) qk[jq] = qs[jq] + kb * KBt * 4;
             if (NLSH_PRIO_MATH >= 0) __builtin_amdgcn_s_setprio(NLSH_PRIO_MATH);
-            l2_kblock<(NQ > 0 ? NQ : 1), NTL>(tile + lane * RSt, RSt, nchunk, qk, acc);
+            l2_kblock<(NQ > 0 ? NQ : 1), NTL, METRIC>(tile + lane * RSt, RSt, nchunk, qk, acc);
             if (NLSH_PRIO_OUT >= 0) __builtin_amdgcn_s_setprio(NLSH_PRIO_OUT);
             if (kb + 1 < nkb) warm_query_lines<(NQ > 0 ? NQ : 1)>(qs, (kb + 1) * KBt * 16, min((kb + 2) * KBt, d4) * 16, qsink);
 #ifdef NLSH_SCAN_TRACE
@@ -696,14 +743,14 @@ __device__ __forceinline__ void l2_task(float4 *tile, const float4 *corpus4, lon
     }
 }
 
-template <int NW, int NQ>
+template <int NW, int NQ, int METRIC = NLSH_METRIC_L2_EPS>
 __device__ __forceinline__ void l2_task_nt(int ntile, float4 *tile, const float4 *corpus4, long long stride4, int d4, int row0, int nrows,
                                            const const_f32p (&qs)[4], int tid, int lane, float (&acc)[4][4], unsigned long long (&tr)[3]) {
     switch (ntile) {
-        case 1: l2_task<NW, NQ, 1>(tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, tr); break;
-        case 2: l2_task<NW, NQ, 2>(tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, tr); break;
-        case 3: l2_task<NW, NQ, 3>(tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, tr); break;
-        default: l2_task<NW, NQ, 4>(tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, tr); break;
+        case 1: l2_task<NW, NQ, 1, METRIC>(tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, tr); break;
+        case 2: l2_task<NW, NQ, 2, METRIC>(tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, tr); break;
+        case 3: l2_task<NW, NQ, 3, METRIC>(tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, tr); break;
+        default: l2_task<NW, NQ, 4, METRIC>(tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, tr); break;
     }
 }
 
@@ -790,16 +837,16 @@ __device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, lo
         mygid[tl] = valid[tl] ? a.gid[prow] : -1;
         myinv[tl] = (METRIC == NLSH_METRIC_COSINE && valid[tl]) ? a.inv_norm[prow] : 0.0f;
     }
-    constexpr bool FAST = NLSH_FAST_KBLOCK && METRIC == NLSH_METRIC_L2_EPS && QW == 4 && TPS == 4;
+    constexpr bool FAST = NLSH_FAST_KBLOCK && (METRIC == NLSH_METRIC_L2_EPS || NLSH_FAST_COSINE) && QW == 4 && TPS == 4;
     [[maybe_unused]] unsigned long long trl[3] = {0, 0, 0};
     [[maybe_unused]] const unsigned long long ts_in = SCAN_NOW();
     if (FAST) {   // hand-scheduled form, specialised per (queries of this wave, tiles of the task); same barrier count on every path
         switch (nqw) {
-            case 0: l2_task_nt<NW, 0>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
-            case 1: l2_task_nt<NW, 1>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
-            case 2: l2_task_nt<NW, 2>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
-            case 3: l2_task_nt<NW, 3>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
-            default: l2_task_nt<NW, 4>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
+            case 0: l2_task_nt<NW, 0, METRIC>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
+            case 1: l2_task_nt<NW, 1, METRIC>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
+            case 2: l2_task_nt<NW, 2, METRIC>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
+            case 3: l2_task_nt<NW, 3, METRIC>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
+            default: l2_task_nt<NW, 4, METRIC>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
         }
     }
     if (!FAST) stage_load(0);

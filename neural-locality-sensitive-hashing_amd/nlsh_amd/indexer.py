@@ -194,8 +194,10 @@ class Indexer:
         """Bucket-major pays when a corpus row is a candidate of several queries of the batch
         (expected (query, probe) pairs per row ~ Q * P * E[bucket size of a row] / N) AND the buckets are
         big enough to fill its row tiles; otherwise (balanced hashes with small buckets, e.g. the GloVe
-        24-bit run: 104k buckets, size-biased mean 82 rows) the query-major stream wins (measured 0.21 ms
-        vs 0.41 / 0.52 ms)."""
+        24-bit run: 104k buckets, size-biased mean 82 rows) the query-major stream keeps the call: r01 measured
+        0.21 ms against 0.41 / 0.52 ms; with r02's hand-scheduled k-blocks (L2 and cosine) the tiled schedule has caught up
+        there (scan 0.199 vs 0.215 ms, sequential step 0.290 vs 0.312 ms at 10^4 queries; within 2 % at 5,000 and fewer;
+        equal through the batch pipeline), which is not enough to move a threshold on."""
         if self.algo is not None:
             return {"query": _capi.SCAN_QUERY_MAJOR, "bucket": _capi.SCAN_BUCKET_MAJOR, "tiled": _capi.SCAN_BUCKET_TILED}[self.algo]
         if self.schedule_stats is not None:

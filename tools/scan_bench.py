@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--queries", type=int, default=10_000)
     ap.add_argument("--tag", default="")
+    ap.add_argument("--metric", default="", choices=["", "l2", "cosine"], help="override the workload's metric (sift1m with cosine = the same buckets and candidates through the cosine bodies)")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--zeros", action="store_true", help="zero the grouped corpus and the queries after the index and the keys exist: same tasks and instruction stream, operands that toggle nothing (DVFS probe; pair with -DNLSH_ABLATE=5, ties change the selection)")
     ap.add_argument("--order", default="", choices=["", "pairs", "work", "density"], help="experiment: schedule order of the buckets recomputed on the host from THIS batch's keys (pairs: by (query, probe) pairs hitting the bucket; work: pairs x rows; density: full 16-query groups first, then by pairs), in place of the static size order")
@@ -49,6 +50,8 @@ def main():
     Ws, bs = io.load_hasher_weights(os.path.join(ROOT, "neural-locality-sensitive-hashing_amd", "checkpoints", ck))
     hashing = io.hashing_from_weights(Ws, bs, compat=compat)
     cg, qg = torch.from_numpy(corpus_h).cuda(), torch.from_numpy(queries_h).cuda()
+    if args.metric:
+        dist_fn = SIFT.distance if args.metric == "l2" else Glove.distance
     ix = Indexer(hashing, cg, dist_fn, compat=compat, algo=args.algo)
     keys, nkeys = ix.hash_device(qg, hash_times=10, seed=7)
     if args.order:
