@@ -55,6 +55,9 @@ extern "C" int nlsh_debug_scan_trace(float *host, int n_floats) {
 #ifndef NLSH_WARM_QLINES
 #define NLSH_WARM_QLINES 1
 #endif
+#ifndef NLSH_COS_SGPR
+#define NLSH_COS_SGPR 1   // 1: the cosine block reads the query chunk straight from SGPRs (68 VGPRs, 7 waves per SIMD, every v_fmac at the SGPR-operand rate: 0.195 ms on the skewed cosine run); 0: from VGPR copies made once per chunk (84 VGPRs, 5 waves: 0.207 ms)
+#endif
 #ifndef NLSH_FAST_COSINE
 #define NLSH_FAST_COSINE 1   // cosine tasks through the hand-scheduled k-blocks too (0: the compiler-scheduled generic loop)
 #endif
@@ -576,9 +579,13 @@ struct QCopy { float4 v[4]; };
 #define NLSH_CBLK(J)                                                                                              \
     "v_fmac_f32 %[a" #J "], %[q" #J "0], %[r0]\n\tv_fmac_f32 %[a" #J "], %[q" #J "1], %[r1]\n\t"                     \
     "v_fmac_f32 %[a" #J "], %[q" #J "2], %[r2]\n\tv_fmac_f32 %[a" #J "], %[q" #J "3], %[r3]\n\t"
+#if NLSH_COS_SGPR
+#define NLSH_CIN(J) [q##J##0] "s"(q.v[J].x), [q##J##1] "s"(q.v[J].y), [q##J##2] "s"(q.v[J].z), [q##J##3] "s"(q.v[J].w)
+#else
 #define NLSH_CIN(J) [q##J##0] "v"(q.v[J].x), [q##J##1] "v"(q.v[J].y), [q##J##2] "v"(q.v[J].z), [q##J##3] "v"(q.v[J].w)
-template <int NQ>
-__device__ __forceinline__ void cos_tile_block(float (&acc)[4], const float4 r, const QCopy &q) {
+#endif
+template <int NQ, typename QT>
+__device__ __forceinline__ void cos_tile_block(float (&acc)[4], const float4 r, const QT &q) {
     if (NQ == 4)
         asm volatile(NLSH_CBLK(0) NLSH_CBLK(1) NLSH_CBLK(2) NLSH_CBLK(3)
                      : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3])
@@ -635,8 +642,12 @@ __device__ __forceinline__ void l2_kblock(const float4 *col, int RSt, int nchunk
             }
             __builtin_amdgcn_sched_barrier(0);
             if (COS) {
-                if (tl == 0) copy_qset<NQ>(qv, cc ? qb : qa);   // this chunk's set was waited for behind the previous chunk's last block
-                cos_tile_block<NQ>(acc[tl], rr[j & 1], qv);
+                if (NLSH_COS_SGPR) {
+                    cos_tile_block<NQ>(acc[tl], rr[j & 1], cc ? qb : qa);
+                } else {
+                    if (tl == 0) copy_qset<NQ>(qv, cc ? qb : qa);   // this chunk's set was waited for behind the previous chunk's last block
+                    cos_tile_block<NQ>(acc[tl], rr[j & 1], qv);
+                }
             } else {
                 l2_tile_block<NQ>(acc[tl], rr[j & 1], cc ? qb : qa);
             }
@@ -650,8 +661,12 @@ __device__ __forceinline__ void l2_kblock(const float4 *col, int RSt, int nchunk
             if (j + 1 < NT) rr[(j + 1) & 1] = col[(j + 1) * TS + c];
             __builtin_amdgcn_sched_barrier(0);
             if (COS) {
-                if (j == 0) copy_qset<NQ>(qv, qa);
-                cos_tile_block<NQ>(acc[j], rr[j & 1], qv);
+                if (NLSH_COS_SGPR) {
+                    cos_tile_block<NQ>(acc[j], rr[j & 1], qa);
+                } else {
+                    if (j == 0) copy_qset<NQ>(qv, qa);
+                    cos_tile_block<NQ>(acc[j], rr[j & 1], qv);
+                }
             } else {
                 l2_tile_block<NQ>(acc[j], rr[j & 1], qa);
             }
