@@ -57,7 +57,19 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (155 TF measured)
 VALU_F32_PEAK_TFLOPS = 157.3  # same figure: 1024 SIMDs x 2.4 GHz x 64 lanes x 2 flop / 2 cycles per wave64 v_fma_f32
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_r02.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_r03.json")
+KERNEL_SOURCES = ("scan_bucket.hip", "scan_common.h", "scan_topk.hip", "common.h")
+
+
+def kernel_source_hash():
+    """sha256 over the scan kernels' sources: the committed PMC figures (TRAFFIC_FILE) carry the hash of the code they were
+    measured on and are reported only while it still matches the tree (tools/make_traffic.py writes it)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "neural-locality-sensitive-hashing_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()
 
 
 def parse(argv=None):
@@ -67,6 +79,10 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="sift1m", choices=["sift1m", "glove"],
                     help="sift1m = BASELINE.json configs[1] (headline); glove = configs[2] (1,183,514 x 100-d, cosine, 24-bit)")
+    ap.add_argument("--data", default="manifold", choices=["manifold", "clusters"],
+                    help="sift1m only.  manifold: synth.sift_manifold (6-d latent manifold: nearest neighbours are meaningful, what the "
+                         "learned hash is trained on; headline).  clusters: SURVEY 8(d)'s own generator, synth.sift_like (1,000 isotropic "
+                         "Gaussian clusters, sigma 24), with the hash trained on it (checkpoints/sift1m_clusters_h16.npz)")
     ap.add_argument("--rows", "--n", dest="n", type=int, default=int(os.environ.get("NLSH_BENCH_N", 0)))
     ap.add_argument("--queries", "--q", dest="q", type=int, default=int(os.environ.get("NLSH_BENCH_Q", 10_000)))
     ap.add_argument("--batches", type=int, default=4, help="distinct query batches the timed steps rotate over")
@@ -156,12 +172,16 @@ def main():
                          "(synthetic SIFT-like integers on a 6-d latent manifold, synth.sift_manifold, standardised)"),
           "glove": dict(N=1_183_514, d=100, H=24, metric="cosine", ckpt="glove_manifold_h24.npz", cfg="configs[2]: GloVe-1.2M-shaped "
                         "(synthetic 100-d embeddings on an 8-d latent manifold, synth.glove_manifold, cosine)")}[args.workload]
+    if args.workload == "sift1m" and args.data == "clusters":
+        wl = dict(wl, ckpt="sift1m_clusters_h16.npz", cfg="configs[1]: SIFT1M-shaped (SURVEY 8(d) generator: synthetic SIFT-like integers, "
+                  "1,000 isotropic Gaussian clusters, sigma 24, synth.sift_like, standardised)")
     N, d, H = args.n or wl["N"], args.dim or wl["d"], args.hash_size or wl["H"]
     args.hash_size_eff = H
     Q, k, P, metric, B = args.q, args.k, args.hash_times, wl["metric"], max(1, args.batches)
     if args.workload == "sift1m":
-        corpus_h, mean, std = synth.standardise(synth.sift_manifold(N, d, seed=synth.SEED_DATA))
-        batches_h = [synth.standardise(synth.sift_manifold(Q, d, seed=synth.SEED_QUERY + 17 * i), mean, std)[0] for i in range(B)]
+        gen = synth.sift_manifold if args.data == "manifold" else synth.sift_like
+        corpus_h, mean, std = synth.standardise(gen(N, d, seed=synth.SEED_DATA))
+        batches_h = [synth.standardise(gen(Q, d, seed=synth.SEED_QUERY + 17 * i), mean, std)[0] for i in range(B)]
     else:
         corpus_h = synth.glove_manifold(N, d, seed=synth.SEED_DATA)
         batches_h = [synth.glove_manifold(Q, d, seed=synth.SEED_QUERY + 17 * i) for i in range(B)]
@@ -223,26 +243,41 @@ def main():
         return float(t.item())
 
     # ------------------------------------------------------------------ region A: the reference's protocol (headline)
-    own = True
+    # `value`: every call returns ALL Q result lists to the calling rank, at every N (the reference's deliverable,
+    # nlsh/trainers/base.py:93-96).  The conversion runs with the facade's opt-in GC promotion ON (Indexer.promote_results,
+    # INTEGRATION.md); the same region with the facade's default (off) is reported beside it, and at N>1 the variant in which
+    # rank r only builds the lists of its Q/N slice of the batch (`own_slice_qps`).
+    def protocol_region(own, promote):
+        Indexer.promote_results = promote
 
-    def query_lists(i):
-        if sharded is not None:   # same seed on every rank; rank r builds the lists of its Q/N slice of the batch
-            return sharded.query(qb[i % B], k=k, hash_times=P, seed=5000 + i, own_slice=own)
-        return indexer.query(qb[i % B], k=k, hash_times=P)
+        def query_lists(i):
+            if sharded is not None:   # same seed on every rank
+                return sharded.query(qb[i % B], k=k, hash_times=P, seed=5000 + i, own_slice=own)
+            return indexer.query(qb[i % B], k=k, hash_times=P)
 
-    for i in range(max(warmup, 1)):        # at least one: sizes the task table (may retry once); untimed
-        ids_api, nc_api = query_lists(-1 - i)   # held like the timed loop holds them: the previous call's lists die when the next arrive
-    fence()
-    call_s = []
-    t0 = time.perf_counter()
-    for i in range(steps):
-        t1 = time.perf_counter()
-        ids_api, nc_api = query_lists(i)
-        call_s.append(time.perf_counter() - t1)
-    fence()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
-    q_lo, q_hi = shard_range(Q, rank, world)
-    assert isinstance(ids_api, list) and len(ids_api) == q_hi - q_lo and isinstance(nc_api, list)
+        held = None
+        for i in range(max(warmup, 1)):        # at least one: sizes the task table (may retry once); untimed
+            held = query_lists(-1 - i)         # held like the timed loop holds them: the previous call's lists die when the next arrive
+        fence()
+        calls = []
+        t0 = time.perf_counter()
+        for i in range(steps):
+            t1 = time.perf_counter()
+            held = query_lists(i)
+            calls.append(time.perf_counter() - t1)
+        fence()
+        el = max_over_ranks(time.perf_counter() - t0)
+        Indexer.promote_results = False
+        return el, calls, held
+
+    elapsed, call_s, (ids_api, nc_api) = protocol_region(own=False, promote=True)
+    assert isinstance(ids_api, list) and len(ids_api) == Q and isinstance(nc_api, list)
+    elapsed_default_gc, _, _ = protocol_region(own=False, promote=False)
+    elapsed_own = None
+    if sharded is not None:
+        elapsed_own, _, (ids_own, _) = protocol_region(own=True, promote=True)
+        q_lo, q_hi = shard_range(Q, rank, world)
+        assert len(ids_own) == q_hi - q_lo
 
     # ------------------------------------------------------------------ region B: same path, results left in HBM
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
@@ -364,7 +399,7 @@ def main():
         tr = json.load(open(TRAFFIC_FILE))
         w = tr["workload"]
         if (w["N"], w["d"], w["Q"], w["H"], w["hash_times"]) == (N, d, Q, H, P) and world == 1 and "learned" in hash_desc \
-                and args.workload == "sift1m":
+                and args.workload == "sift1m" and args.data == "manifold" and tr.get("kernel_source_sha256") == kernel_source_hash():
             traffic = tr["traffic_bytes_per_launch"].get(str(indexer.last_algo))
             valu_insts = tr.get("valu_wave_instructions_per_launch", {}).get(str(indexer.last_algo))
             clock_held = tr.get("clock_held_GHz", {}).get(str(indexer.last_algo))
@@ -377,7 +412,7 @@ def main():
         corpus_d = torch.from_numpy(corpus_h).to(dev)
         gt = brute_force_topk(qb[0], corpus_d, k, metric).cpu().numpy()
         del corpus_d
-    own = False                      # untimed: all lists on every rank (rank 0 computes the recall from them)
+    # untimed: all lists on every rank (rank 0 computes the recall from them)
     # every rank takes part in the (collective) protocol call the recall is computed from; ONE fixed probe seed at every N,
     # so recall@10 and the candidate counts are the same numbers at 1, 2, 4 and 8 GPUs
     if sharded is not None:
@@ -419,8 +454,12 @@ def main():
             "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "recall_at_10": recall,
-            "value_protocol": "Indexer.query(batch, k, hash_times) -> Python lists, K synchronous calls (nlsh/trainers/base.py:93-96)" +
-                              ("" if world == 1 else f"; sharded: every rank scans all queries over its shard and returns the lists of its 1/{world} slice of the batch"),
+            "value_protocol": "Indexer.query(batch, k, hash_times) -> Python lists of ALL Q queries on the calling rank, K synchronous calls "
+                              "(nlsh/trainers/base.py:93-96); Indexer.promote_results=True (opt-in GC promotion of the result lists, "
+                              "INTEGRATION.md)" + ("" if world == 1 else f"; sharded x{world}: every rank scans all queries over its shard, one "
+                                                    "all-gather + merge, every rank builds all Q lists"),
+            "protocol_qps_default_gc": Q * steps / elapsed_default_gc,
+            "own_slice_qps": None if elapsed_own is None else Q * steps / elapsed_own,
             "protocol_median_qps": Q / float(np.median(call_s)),
             "protocol_call_ms": [round(1e3 * c, 3) for c in call_s],
             "device_resident_qps": Q * steps / elapsed_dev, "device_resident_ms_per_step": 1e3 * elapsed_dev / steps,

@@ -43,7 +43,7 @@ enum { NLSH_ACT_SIGMOID = 0, NLSH_ACT_TANH = 1 };      /* nlsh/hashings.py:22-26
 enum { NLSH_KEY_REF_INT16 = 0, NLSH_KEY_FULL = 1 };    /* nlsh/utils.pyx:7-15 (int16 wrap) | eval.py:49-53 */
 enum { NLSH_METRIC_L2_EPS = 0, NLSH_METRIC_COSINE = 1 }; /* nlsh/data.py:191-201 | 99-109 */
 /* schedules of nlsh_scan_topk: one wave per (query, segment) | one wave per (bucket segment, <= 8 queries) |
- * one workgroup per (bucket segment, <= 32 queries) with the row tile staged through LDS.  0 and 1 give
+ * one workgroup per (bucket segment, <= 16 queries) with the row tile staged through LDS.  0 and 1 give
  * bit-identical results; 2 sums each distance in k order (bit-identical to the oracle), ids agree except fp32 near-ties. */
 enum { NLSH_SCAN_QUERY_MAJOR = 0, NLSH_SCAN_BUCKET_MAJOR = 1, NLSH_SCAN_BUCKET_TILED = 2 };
 
@@ -137,10 +137,12 @@ size_t nlsh_scan_workspace(int64_t Q, int P, int k, int64_t max_tasks, int64_t n
 /* corpus_sorted [dev] fp32 [N, row_stride] bucket-contiguous (nlsh_gather_rows), gid [dev] [N],
  * uniq_keys [dev] [n_buckets] ascending, offsets [dev] [n_buckets+1], bucket_order (nullable) [dev]
  * [n_buckets] from nlsh_bucket_order (NULL = CSR order), inv_norm [dev] [N] (cosine only), queries [dev] [Q, d] stride q_stride, qkeys [dev] [Q, P] with nkeys [dev] [Q] valid slots
- * (distinct keys; unknown keys are empty buckets, never an error: indexer.py:61,68).
+ * (a query's keys are a set, nlsh/utils.pyx:27-31: a key repeated within a row probes its bucket once; unknown keys are
+ * empty buckets, never an error: indexer.py:61,68).
  * Outputs [dev]: out_dist [Q, k] ascending, +inf padded; out_idx [Q, k] global row ids, -1 padded;
  * out_keys (nullable) [Q, k] the 64-bit sort keys (monotone(dist) << 32 | id; ~0 padded) used by
- * nlsh_merge_topk; out_ncand [Q] candidates per query; status [2] = {tasks needed, overflow flag}.
+ * nlsh_merge_topk; out_ncand [Q] candidates per query; status [2] = {tasks needed, flag}: flag 0 = complete,
+ * 1 = task table overflow (repeat with max_tasks >= status[0]), 2 = workspace contract violated (below).
  * Order is (distance asc, row id asc): deterministic refinement of torch.topk's tie order.
  * A query's candidate list is cut into segments of `seg_rows` rows (0 = default), one wavefront
  * each; max_tasks bounds the number of segments the workspace holds: if status[1] != 0 the
@@ -149,7 +151,11 @@ size_t nlsh_scan_workspace(int64_t Q, int P, int k, int64_t max_tasks, int64_t n
  * 4 * n_buckets bytes of the workspace (an offset that does not depend on Q, P or max_tasks).  Those bytes must be ZERO
  * before the first call that uses the buffer and must not be written by anything else afterwards (do not lend the buffer
  * to algo 0 calls in between); every completed call leaves them zero again (the scatter step hands every count back),
- * which is what saves a clearing launch per batch.
+ * which is what saves a clearing launch per batch.  The contract is CHECKED on the device, twice: the PLAN phase holds the sum
+ * of the counters against the (query, probe) pairs it counted itself and rejects negative counters -- on a mismatch the batch
+ * gets no task at all and every query's result is empty --, and the MERGE phase verifies that every counter is back at zero
+ * (stale counts that cancel in the sum mis-size individual query lists: all accesses stay in bounds, the lists are wrong).
+ * Either way status[1] = 2: zero the first 4 * n_buckets bytes and repeat the call (the Python facade raises NLSH_E_WORKSPACE).
  * ev_scan_begin / ev_scan_end (nullable hipEvent_t): recorded on `stream` immediately before and
  * after the scan kernel, so a caller can time the HBM-bound kernel alone (bench.py roofline).
  * Limits: d <= NLSH_MAX_DIM, k <= NLSH_MAX_K, P <= NLSH_MAX_PROBES. */
@@ -160,6 +166,13 @@ int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, int d, const 
                    float *out_dist, int32_t *out_idx, uint64_t *out_keys, int32_t *out_ncand,
                    int32_t *status, void *workspace, size_t workspace_bytes, int64_t max_tasks,
                    void *ev_scan_begin, void *ev_scan_end, nlsh_stream_t stream);
+
+/* Diagnostic, for tests of the bucket-major schedules (algo 1, 2): byte offsets, inside a workspace of this shape, of the
+ * task table the PLAN phase leaves there -- int32 [status[0]][4] = {first pair of the query group, queries in the group,
+ * first corpus row of the segment, rows in the segment} -- and (algo 2 only) of the tasks' query ids, int32 [max_tasks][16].
+ * No reference counterpart: the reference has no schedule (it walks `for key in index_keys`, nlsh/indexer.py:66). */
+int nlsh_scan_workspace_layout(int64_t Q, int P, int k, int64_t max_tasks, int64_t n_buckets, int d, int algo,
+                               size_t *task_table_offset, size_t *task_queries_offset);
 
 /* The same call cut in three, for callers that pipeline batches over streams: NLSH_PHASE_PLAN runs everything up
  * to the scan kernel (bucket lookup, task table; touches status and the workspace, the query-major schedule also out_ncand),

@@ -115,7 +115,8 @@ struct BArgs {
     uint64_t *partial;
     long long max_tasks;
     const int32_t *border;     // [nb] schedule order of the buckets (largest first) or nullptr = CSR order
-    int32_t *btot;             // [2 * blocks of bscan] per-block (pairs, tasks) totals
+    int32_t *btot;             // [3 * blocks of bscan] per-block (pairs, tasks, negative counters) totals
+    int32_t *hits;             // [blocks of bplan] (query, probe) pairs each bplan block found a bucket for
     unsigned long long *tauq;  // [Q] running upper bound of each query's k-th best key (atomicMin), KEY_NONE-initialised
     const float *qpad;  // tiled variant: queries padded to d4p*4 floats (L2: pad = -eps; cosine: pre-normalised, pad = 0)
     float *qpad_w;      // same buffer, writable (bprep); qpad aliases `queries` when no padding/normalisation is needed
@@ -128,42 +129,54 @@ struct BArgs {
 // stride-long run in global memory: 3-4 dependent global loads per thread instead of 13.
 __global__ __launch_bounds__(256) void bplan_kernel(BArgs a, int stride) {
     __shared__ int32_t coarse[1024];
+    __shared__ int whits[4];
     const int nco = (a.nb + stride - 1) / stride;
     for (int i = threadIdx.x; i < nco; i += 256) coarse[i] = a.uniq[(long long)i * stride];
     __syncthreads();
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx == 0) { a.status[0] = 0; a.status[1] = 0; }   // per-batch initialisation rides along (no separate launch)
-    if (idx >= a.Q * a.P) return;
-    const long long q = idx / a.P;
-    const int p = (int)(idx - q * a.P);
-    if (p == 0) a.tauq[q] = KEY_NONE;        // running bound of the query
-    int nk = a.nkeys[q];
-    nk = nk < 0 ? 0 : (nk > a.P ? a.P : nk);
     int b = -1;
-    if (p < nk) {
-        const int32_t key = a.qkeys[idx];
-        int lo = 0, hi = nco;
-        while (lo < hi) {  // first coarse entry > key
-            const int mid = (lo + hi) >> 1;
-            if (coarse[mid] <= key) lo = mid + 1; else hi = mid;
-        }
-        if (lo > 0) {  // the key, if present, lies in the run that starts at coarse entry lo-1
-            lo = (lo - 1) * stride;
-            hi = min(a.nb, lo + stride);
-            while (lo < hi) {
+    if (idx < a.Q * a.P) {
+        const long long q = idx / a.P;
+        const int p = (int)(idx - q * a.P);
+        if (p == 0) a.tauq[q] = KEY_NONE;        // running bound of the query
+        int nk = a.nkeys[q];
+        nk = nk < 0 ? 0 : (nk > a.P ? a.P : nk);
+        if (p < nk) {
+            const int32_t key = a.qkeys[idx];
+            // a query's keys are a SET (nlsh/utils.pyx:27-31): a repeated key probes its bucket once.  encode_hash never
+            // emits one; a C caller's table might, and the selection-based merges assume distinct (distance, id) keys.
+            bool dup = false;
+            for (int pp = 0; pp < p; ++pp) dup |= a.qkeys[idx - p + pp] == key;
+            int lo = 0, hi = dup ? 0 : nco;
+            while (lo < hi) {  // first coarse entry > key
                 const int mid = (lo + hi) >> 1;
-                if (a.uniq[mid] < key) lo = mid + 1; else hi = mid;
+                if (coarse[mid] <= key) lo = mid + 1; else hi = mid;
             }
-            if (lo < a.nb && a.uniq[lo] == key) {  // unknown key = empty bucket (indexer.py:61,68)
-                const int sz = a.offsets[lo + 1] - a.offsets[lo];
-                if (sz > 0) {
-                    b = lo;
-                    atomicAdd(&a.bcount[lo], 1);
+            if (lo > 0) {  // the key, if present, lies in the run that starts at coarse entry lo-1
+                lo = (lo - 1) * stride;
+                hi = min(a.nb, lo + stride);
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (a.uniq[mid] < key) lo = mid + 1; else hi = mid;
+                }
+                if (lo < a.nb && a.uniq[lo] == key) {  // unknown key = empty bucket (indexer.py:61,68)
+                    const int sz = a.offsets[lo + 1] - a.offsets[lo];
+                    if (sz > 0) {
+                        b = lo;
+                        atomicAdd(&a.bcount[lo], 1);
+                    }
                 }
             }
         }
+        a.pbkt[idx] = b;
     }
-    a.pbkt[idx] = b;
+    // pairs this block added to the counters: bscan_kernel holds the counters' sum against the sum of these, which is how
+    // a workspace head that was not zero on entry (workspace contract, nlsh_hip.h) is caught instead of trusted
+    const unsigned long long m = __ballot(b >= 0);
+    if ((threadIdx.x & 63) == 0) whits[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) a.hits[blockIdx.x] = whits[0] + whits[1] + whits[2] + whits[3];
 }
 
 __device__ __forceinline__ int block_excl_scan(int v, int *wsum, int *total) {
@@ -201,32 +214,54 @@ __global__ __launch_bounds__(256) void bcount_kernel(BArgs a) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     int b, m = 0, s, ns = 0, ng = 0;
     if (i < a.nb) bucket_task_counts(a, i, b, m, s, ns, ng);
-    int tot_m, tot_t;
+    int tot_m, tot_t, tot_neg;
     block_excl_scan(m, wsum, &tot_m);
     block_excl_scan(ng * ns, wsum, &tot_t);
+    block_excl_scan(m < 0 ? 1 : 0, wsum, &tot_neg);
     if (threadIdx.x == 0) {
-        a.btot[2 * blockIdx.x] = tot_m;
-        a.btot[2 * blockIdx.x + 1] = tot_t;
+        a.btot[3 * blockIdx.x] = tot_m;
+        a.btot[3 * blockIdx.x + 1] = tot_t;
+        a.btot[3 * blockIdx.x + 2] = tot_neg;
     }
 }
 
-__global__ __launch_bounds__(256) void bscan_kernel(BArgs a) {
+// status[1] = 2: the per-bucket pair counters at the head of the workspace were not zero when the batch's PLAN phase
+// started (an uninitialised buffer, one lent to another schedule, a call aborted between bplan and bscatter).  Every block
+// derives the verdict from the same numbers -- the counters must sum to the pairs bplan counted this batch and none may be
+// negative --, so either all of them lay out tasks or none does: a poisoned batch gets NO task, bscatter writes empty
+// records and the merge returns empty lists; nothing is ever addressed through a stale count.  The facade turns the flag
+// into NLSH_E_WORKSPACE.
+__global__ __launch_bounds__(256) void bscan_kernel(BArgs a, int plan_blocks) {
     __shared__ int wsum[4];
-    __shared__ int base_m, base_t;
+    __shared__ int base_m, base_t, poisoned;
     const int i = blockIdx.x * 256 + threadIdx.x;
+    int all_m = 0, all_neg = 0, all_hits = 0;
+    for (int j = threadIdx.x; j < (int)gridDim.x; j += 256) {
+        all_m += a.btot[3 * j];
+        all_neg += a.btot[3 * j + 2];
+    }
+    for (int j = threadIdx.x; j < plan_blocks; j += 256) all_hits += a.hits[j];
+    int dummy;
+    block_excl_scan(all_m - all_hits, wsum, &dummy);
+    if (threadIdx.x == 0) poisoned = dummy != 0;
+    block_excl_scan(all_neg, wsum, &dummy);
+    if (threadIdx.x == 0) poisoned |= dummy != 0;
+    __syncthreads();
+    const bool bad = poisoned != 0;
     int b = 0, m = 0, s = 0, ns = 0, ng = 0;
     if (i < a.nb) {
         bucket_task_counts(a, i, b, m, s, ns, ng);
+        if (bad) { m = 0; ng = 0; }
         a.bgroups[b] = ng;
     }
     const int nt = ng * ns;
     // totals of the blocks before this one (and, in the last block, of all blocks -> status[0])
     int pm = 0, pt = 0;
     for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) {
-        pm += a.btot[2 * j];
-        pt += a.btot[2 * j + 1];
+        pm += a.btot[3 * j];
+        pt += a.btot[3 * j + 1];
     }
-    int tot_m, tot_t, dummy;
+    int tot_m, tot_t;
     const int ex_m = block_excl_scan(m, wsum, &tot_m);
     const int ex_t = block_excl_scan(nt, wsum, &tot_t);
     block_excl_scan(pm, wsum, &dummy);
@@ -234,10 +269,13 @@ __global__ __launch_bounds__(256) void bscan_kernel(BArgs a) {
     block_excl_scan(pt, wsum, &dummy);
     if (threadIdx.x == 0) {
         base_t = dummy;
-        if (blockIdx.x == gridDim.x - 1) a.status[0] = dummy + tot_t;  // tasks needed (may exceed max_tasks: the caller retries)
+        if (blockIdx.x == gridDim.x - 1) {
+            a.status[0] = bad ? 0 : dummy + tot_t;  // tasks needed (may exceed max_tasks: the caller retries)
+            if (bad) a.status[1] = 2;
+        }
     }
     __syncthreads();
-    if (i < a.nb) {
+    if (i < a.nb && !bad) {
         const int po = base_m + ex_m, to = base_t + ex_t;
         a.pairoff[b] = po;
         a.taskoff[b] = to;
@@ -257,11 +295,16 @@ __global__ __launch_bounds__(256) void bscatter_kernel(BArgs a) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= a.Q * a.P) return;
     const int b = a.pbkt[idx];
-    if (b < 0) {
+    if (b < 0 || a.status[1] == 2) {   // no bucket, or a poisoned workspace (bscan_kernel): nothing is addressed through the counters
         a.prec[idx] = make_int4(0, 0, 0, 0);
         return;
     }
     const int rel = atomicSub(&a.bcount[b], 1) - 1;  // slot of this query in the bucket's pair list
+    if (rel < 0) {   // the counter started below zero-plus-this-batch's-pairs: a stale negative count (workspace contract); no slot exists
+        a.status[1] = 2;
+        a.prec[idx] = make_int4(0, 0, 0, 0);
+        return;
+    }
     a.inv_q[a.pairoff[b] + rel] = (int32_t)(idx / a.P);
     // what bmerge needs to find this probe's partial lists, resolved here so that it has one load level less:
     // task of (segment si, group gi) = taskoff + si * ngroups + gi
@@ -293,7 +336,9 @@ __device__ __forceinline__ void bscan2_task(const BArgs &a, long long t, int pai
     for (int jq = 0; jq < QB; ++jq) {
         top[jq] = KEY_NONE;
         tau[jq] = KEY_NONE;
-        const int qi = __builtin_amdgcn_readfirstlane(a.inv_q[pair0 + ((FULL || jq < nq) ? jq : 0)]);
+        // clamped into [0, Q): a slot that a stale counter invented (workspace contract violated; bmerge flags it) holds whatever
+        // the buffer held, and nothing may be addressed through it
+        const int qi = min(max(__builtin_amdgcn_readfirstlane(a.inv_q[pair0 + ((FULL || jq < nq) ? jq : 0)]), 0), (int)a.Q - 1);
         load_query<LPR, VPL, METRIC>(a.queries + (long long)qi * a.q_stride, a.d, li, qv[jq], act);
     }
 
@@ -1016,7 +1061,8 @@ __global__ __launch_bounds__(64 * NW, NLSH_TILED_MIN_WAVES) void bscan3_kernel(B
     const int4 desc = a.task[tc];
     int qid_v[QW];                                    // the task's query ids: address known from the task id alone
 #pragma unroll
-    for (int jq = 0; jq < QW; ++jq) qid_v[jq] = a.task_q[tc * (QW * NW) + NLSH_SLOT(wave, jq)];   // slots >= nq hold garbage, never used
+    for (int jq = 0; jq < QW; ++jq)   // slots >= nq hold garbage, never used; clamped into [0, Q) so that a slot a stale counter invented (bmerge flags it) addresses nothing outside the queries
+        qid_v[jq] = min(max(a.task_q[tc * (QW * NW) + NLSH_SLOT(wave, jq)], 0), (int)a.Q - 1);
     if (t >= ntasks) return;
     if (NLSH_ABLATE == 9) return;   // diagnostic: every workgroup leaves after its descriptor loads (what dispatching the grid costs)
     if (NLSH_ABLATE == 8 && desc.y <= NLSH_ABLATE_NQ) return;   // diagnostic: tasks with few queries vanish (what the low-density tasks cost)
@@ -1025,6 +1071,13 @@ __global__ __launch_bounds__(64 * NW, NLSH_TILED_MIN_WAVES) void bscan3_kernel(B
 }
 
 __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
+    // Every pair counter is back at zero once the scatter step has run -- unless it did not start from zero (workspace
+    // contract).  The PLAN phase's sum check catches stale counts that change the totals (those would overrun the pair
+    // lists); this per-bucket check catches the rest (stale counts that cancel in the sum mis-size individual lists: every
+    // access stays in bounds -- clamped query ids, guarded slots -- but the lists are wrong), so a violated contract is
+    // ALWAYS reported (status[1] = 2), never a silently wrong result.
+    for (long long b = (long long)blockIdx.x * 256 + threadIdx.x; b < a.nb; b += (long long)gridDim.x * 256)
+        if (a.bcount[b] != 0) a.status[1] = 2;
     const int lane = threadIdx.x & 63;
     const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= a.Q) return;
@@ -1095,7 +1148,7 @@ constexpr int TILED_QB = NLSH_TILED_QB;  // queries per task of the tiled schedu
 constexpr int TILED_TPS = NLSH_TILED_TPS;  // 64-row tiles per task of the tiled schedule (segment = 64*TPS rows)
 
 struct BWs {
-    size_t pbkt, prec, inv_q, bcount, pairoff, taskoff, bgroups, counters, btot, task, task_q, partial, qpad, tauq, total;
+    size_t pbkt, prec, inv_q, bcount, pairoff, taskoff, bgroups, counters, btot, hits, task, task_q, partial, qpad, tauq, total;
 };
 static void blayout(long long Q, int P, int k, long long max_tasks, long long nb, int d, bool tiled, BWs *w) {
     size_t o = 0;
@@ -1108,7 +1161,8 @@ static void blayout(long long Q, int P, int k, long long max_tasks, long long nb
     w->taskoff = o;  o += ws_align(nb4);
     w->bgroups = o;  o += ws_align(nb4);
     w->counters = o; o += ws_align(64);
-    w->btot = o;     o += ws_align((size_t)((nb + 255) / 256 + 1) * 8);
+    w->btot = o;     o += ws_align((size_t)((nb + 255) / 256 + 1) * 12);
+    w->hits = o;     o += ws_align((size_t)((Q * P + 255) / 256 + 1) * 4);
     w->task = o;     o += ws_align((size_t)max_tasks * sizeof(int4));
     w->task_q = o;   o += tiled ? ws_align((size_t)max_tasks * TILED_QB * 4) : 0;
     w->partial = o;  o += ws_align((size_t)max_tasks * (tiled ? TILED_QB : 8) * k * 8);
@@ -1123,6 +1177,21 @@ size_t bucket_scan_workspace(long long Q, int P, int k, long long max_tasks, lon
     blayout(Q, P, k, max_tasks, n_buckets, d, true, &wt);
     return w.total > wt.total ? w.total : wt.total;
 }
+
+}  // namespace nlsh
+
+extern "C" int nlsh_scan_workspace_layout(int64_t Q, int P, int k, int64_t max_tasks, int64_t n_buckets, int d, int algo,
+                                          size_t *task_table_offset, size_t *task_queries_offset) {
+    NLSH_REQUIRE(algo == NLSH_SCAN_BUCKET_MAJOR || algo == NLSH_SCAN_BUCKET_TILED, NLSH_E_INVALID, "scan_workspace_layout: algo=%d has no task table of this form", algo);
+    NLSH_REQUIRE(Q >= 0 && P >= 1 && k >= 1 && max_tasks >= 0 && n_buckets >= 0 && d >= 1, NLSH_E_INVALID, "scan_workspace_layout: bad sizes");
+    nlsh::BWs w;
+    nlsh::blayout(Q, P, k, max_tasks, n_buckets, d, algo == NLSH_SCAN_BUCKET_TILED, &w);
+    if (task_table_offset) *task_table_offset = w.task;
+    if (task_queries_offset) *task_queries_offset = w.task_q;
+    return NLSH_OK;
+}
+
+namespace nlsh {
 
 template <int METRIC>
 static void launch_bscan2(const BArgs &a, int d4, unsigned grid, hipStream_t s) {
@@ -1150,7 +1219,7 @@ int bucket_scan_run(const BucketScanCall &c) {
     char *base = (char *)c.workspace;
     a.pbkt = (int32_t *)(base + w.pbkt); a.prec = (int4 *)(base + w.prec); a.inv_q = (int32_t *)(base + w.inv_q);
     a.bcount = (int32_t *)(base + w.bcount); a.pairoff = (int32_t *)(base + w.pairoff); a.taskoff = (int32_t *)(base + w.taskoff); a.bgroups = (int32_t *)(base + w.bgroups);
-    a.counters = (int32_t *)(base + w.counters); a.btot = (int32_t *)(base + w.btot); a.border = c.bucket_order; a.task = (int4 *)(base + w.task); a.task_q = c.tiled ? (int32_t *)(base + w.task_q) : nullptr; a.partial = (uint64_t *)(base + w.partial);
+    a.counters = (int32_t *)(base + w.counters); a.btot = (int32_t *)(base + w.btot); a.hits = (int32_t *)(base + w.hits); a.border = c.bucket_order; a.task = (int4 *)(base + w.task); a.task_q = c.tiled ? (int32_t *)(base + w.task_q) : nullptr; a.partial = (uint64_t *)(base + w.partial);
     a.max_tasks = c.max_tasks;
     a.tauq = (unsigned long long *)(base + w.tauq);
 
@@ -1168,7 +1237,7 @@ int bucket_scan_run(const BucketScanCall &c) {
         if (c.nb > 0) {
             const unsigned gb = (unsigned)((c.nb + 255) / 256);
             hipLaunchKernelGGL(bcount_kernel, dim3(gb), dim3(256), 0, s, a);
-            hipLaunchKernelGGL(bscan_kernel, dim3(gb), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(bscan_kernel, dim3(gb), dim3(256), 0, s, a, (int)gp);
         }
         hipLaunchKernelGGL(bscatter_kernel, dim3(gp), dim3(256), 0, s, a);
         if (prep) hipLaunchKernelGGL(bprep_kernel, dim3((unsigned)c.Q), dim3(64), 0, s, a, c.metric);

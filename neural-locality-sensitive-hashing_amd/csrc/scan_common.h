@@ -108,7 +108,10 @@ __device__ __forceinline__ uint32_t wave_minmax_u32(uint32_t x) {
 // on the id word.  Survivors are compacted with mbcnt prefix counts.  Returns an exclusive upper bound of this list's
 // k-th best key to publish for the query (every key at or above it is beyond the list's k best) or KEY_NONE when the
 // list holds fewer than k keys.
-template <int NK>
+// CLAMP (the merges): keys that reach a merge are distinct when every (query, bucket) pair was scanned once -- the plan
+// kernels de-duplicate a query's probe keys, corpus shards are disjoint -- but nlsh_merge_topk takes whatever lists a C
+// caller hands it: with repeated keys the tie search can select more than k, so the compaction never writes past out[k).
+template <int NK, bool CLAMP = false>
 __device__ __forceinline__ uint64_t select_k_smallest(const uint64_t (&key)[NK], int k, int lane, uint64_t *out) {
     uint32_t hi[NK], lo[NK];
     int n = 0;
@@ -167,7 +170,7 @@ __device__ __forceinline__ uint64_t select_k_smallest(const uint64_t (&key)[NK],
         const bool sel = key[i] != KEY_NONE && (hi[i] < dk || (hi[i] == dk && lo[i] <= idk));
         const unsigned long long m = __ballot(sel);
         const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (sel) out[pos] = key[i];
+        if (sel && (!CLAMP || pos < k)) out[pos] = key[i];
         base += __popcll(m);
     }
     if (lane >= base && lane < k) out[lane] = KEY_NONE;
@@ -181,15 +184,15 @@ __device__ __forceinline__ uint64_t select_k_smallest(const uint64_t (&key)[NK],
 // all of its k keys.  merge_finish ranks the k survivors (k uniform compare steps) and stores them in ascending order.
 template <int NK>
 __device__ __forceinline__ uint64_t merge_round(uint64_t (&key)[NK], int k, int lane, uint64_t *scratch) {
-    select_k_smallest<NK>(key, k, lane, scratch);
+    select_k_smallest<NK, true>(key, k, lane, scratch);
     return lane < k ? scratch[lane] : KEY_NONE;   // same wave wrote it: LDS operations of a wave complete in order
 }
 
 __device__ __forceinline__ void merge_finish(uint64_t carry, int k, int lane, float *out_dist, int32_t *out_idx, uint64_t *out_keys, long long q) {
     int rank = 0;
-    for (int j = 0; j < k; ++j) {   // keys are distinct ((distance, id) with distinct ids), KEY_NONE sits behind the real ones
-        const uint64_t kj = read_lane64(carry, j);
-        rank += kj < carry ? 1 : 0;
+    for (int j = 0; j < k; ++j) {   // keys are distinct ((distance, id) with distinct ids), KEY_NONE sits behind the real ones;
+        const uint64_t kj = read_lane64(carry, j);   // equal keys (a C caller's repeated lists) are ordered by lane: every slot is written
+        rank += (kj < carry || (kj == carry && j < lane)) ? 1 : 0;
     }
     if (lane < k) {
         const bool none = carry == KEY_NONE;

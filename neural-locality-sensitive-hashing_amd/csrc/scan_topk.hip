@@ -74,12 +74,14 @@ __global__ __launch_bounds__(256) void plan_kernel(ScanArgs a) {
             int32_t st = 0, sz = 0;
             if (p < nk) {
                 const int32_t key = a.qkeys[q * a.P + p];
-                int lo = 0, hi = a.nb;  // lower_bound in the ascending bucket keys
+                bool dup = false;       // a query's keys are a set (nlsh/utils.pyx:27-31): a repeated key probes its bucket once
+                for (int pp = 0; pp < p; ++pp) dup |= a.qkeys[q * a.P + pp] == key;
+                int lo = 0, hi = dup ? 0 : a.nb;  // lower_bound in the ascending bucket keys
                 while (lo < hi) {
                     int mid = (lo + hi) >> 1;
                     if (a.uniq[mid] < key) lo = mid + 1; else hi = mid;
                 }
-                if (lo < a.nb && a.uniq[lo] == key) {  // unknown key = empty bucket (indexer.py:61,68)
+                if (!dup && lo < a.nb && a.uniq[lo] == key) {  // unknown key = empty bucket (indexer.py:61,68)
                     st = a.offsets[lo];
                     sz = a.offsets[lo + 1] - st;
                 }

@@ -26,7 +26,7 @@ SYMBOLS = (
     "nlsh_abi_version", "nlsh_last_error",
     "nlsh_encoder_packed_floats", "nlsh_encoder_pack", "nlsh_encode_hash", "nlsh_pack_codes",
     "nlsh_build_csr_workspace", "nlsh_build_csr", "nlsh_bucket_order_workspace", "nlsh_bucket_order", "nlsh_gather_rows",
-    "nlsh_scan_workspace", "nlsh_scan_topk", "nlsh_scan_topk_phase", "nlsh_merge_topk",
+    "nlsh_scan_workspace", "nlsh_scan_workspace_layout", "nlsh_scan_topk", "nlsh_scan_topk_phase", "nlsh_merge_topk",
 )
 
 
@@ -79,6 +79,8 @@ def lib():
     L.nlsh_gather_rows.argtypes = [vp, i64, i32, vp, i64, vp, i64, vp, vp, ctypes.c_int32, vp]
     L.nlsh_scan_workspace.restype = sz
     L.nlsh_scan_workspace.argtypes = [i64, i32, i32, i64, i64, i32]
+    L.nlsh_scan_workspace_layout.restype = i32
+    L.nlsh_scan_workspace_layout.argtypes = [i64, i32, i32, i64, i64, i32, i32, vp, vp]
     L.nlsh_scan_topk.restype = i32
     L.nlsh_scan_topk.argtypes = [vp, i64, i32, vp, vp, vp, vp, ctypes.c_int32, vp, vp, i64, i64, vp, vp, i32, i32, i32, i32, i32,
                                  vp, vp, vp, vp, vp, vp, sz, i64, vp, vp, vp]

@@ -83,7 +83,8 @@ class MultivariateBernoulli:
         return self._run(x, 1, want_probs=True)[2]
 
     def hash(self, query_vectors, n=1) -> List[Set[int]]:
-        """hashings.py:66-92: list of B sets of bucket keys (1 hard + n-1 sampled probes)."""
+        """hashings.py:66-92: list of B sets of bucket keys (1 hard + n-1 sampled probes).
+        Like the reference, the forward runs in whatever mode the module is in (`train_mode`): see `_run_train_mode`."""
         if n < 1:
             raise ValueError(f"`n` should be positive integer, but got {n}")
         keys, nkeys, _ = self._run(query_vectors, n)
@@ -160,9 +161,51 @@ class MultivariateBernoulli:
     def next_seed(self):
         return (self._seed + 0x9E3779B97F4A7C15 * (next(self._calls) + 1)) & 0xFFFFFFFFFFFFFFFF
 
+    def _needs_train_forward(self):
+        """Train mode changes the forward only for encoders with BatchNorm (batch statistics instead of the running ones the
+        fused kernel folds into its weights); the plain Linear+ReLU stacks compute the same function in both modes."""
+        return self._hasher.training and any(isinstance(m, nn.modules.batchnorm._BatchNorm) for m in self._hasher.modules())
+
+    def _run_train_mode(self, x, n, n_multi_rows, want_probs, out):
+        """`hash()` / `hash_device()` while the module is in TRAIN mode and has BatchNorm layers: the reference's `hash` runs
+        `self._hasher(query_vectors)` in the module's current mode (nlsh/hashings.py:66-67; nlsh/trainers/proposed.py:101-104
+        calls it between optimiser steps, in train mode), i.e. with BATCH statistics and a running-statistics update.  That
+        forward cannot be folded into the fused kernel's weights, and training is outside the query-time hot path, so this
+        branch mirrors the reference op for op on the device: the module's own forward, `> 0.5`, `torch.bernoulli` draws (the
+        global torch RNG, as `Bernoulli.sample` uses), then `nlsh_pack_codes` and a first-occurrence de-duplication per row."""
+        from .utils import pack_codes
+        with torch.no_grad():
+            probs = self._hasher(x)
+        p01 = probs / 2. + 0.5 if self._tanh_output else probs
+        base = (p01 > 0.5).int().unsqueeze(1)
+        if n > 1:
+            sampled = torch.bernoulli(p01.unsqueeze(0).expand(n - 1, -1, -1)).int().permute(1, 0, 2)
+            codes = torch.cat((base, sampled), dim=1)
+        else:
+            codes = base
+        B = x.shape[0]
+        every = pack_codes(codes.contiguous(), "ref_int16" if self.key_mode == _capi.KEY_REF_INT16 else "full", device=x.device)
+        earlier = torch.tril(torch.ones((n, n), dtype=torch.bool, device=x.device), diagonal=-1)
+        dup = ((every[:, :, None] == every[:, None, :]) & earlier[None]).any(2)
+        if n_multi_rows is not None and n > 1:      # Indexer.hash's trailing-batch rule: rows >= n_multi_rows are single-probe
+            dup[int(n_multi_rows):, 1:] = True
+        order = torch.argsort(dup.to(torch.int8), dim=1, stable=True)
+        keys_t, nkeys_t = torch.gather(every, 1, order).contiguous(), (~dup).sum(1).to(torch.int32)
+        if out is not None:
+            out[0].copy_(keys_t)
+            out[1].copy_(nkeys_t)
+            keys_t, nkeys_t = out
+        return keys_t, nkeys_t, (probs if want_probs else None)
+
     def _run(self, x, n, n_multi_rows=None, seed=None, row0=0, want_probs=False, z_out=None, code_out=None, out=None):
         if x.device.type != "cuda":
             raise _capi.NlshHipError(_capi.E_INVALID, "encode_hash needs a device tensor; there is no CPU path")
+        if self._needs_train_forward():
+            if z_out is not None or code_out is not None:
+                raise _capi.NlshHipError(_capi.E_UNSUPPORTED, "forward_device() needs eval mode for BatchNorm encoders (train_mode(False))")
+            if x.dtype != torch.float32:
+                x = x.float()
+            return self._run_train_mode(x.detach(), n, n_multi_rows, want_probs, out)
         if n > _capi.MAX_ENCODE_PROBES:
             raise _capi.NlshHipError(_capi.E_UNSUPPORTED, f"hash_times={n} > {_capi.MAX_ENCODE_PROBES}")
         L = _capi.lib()

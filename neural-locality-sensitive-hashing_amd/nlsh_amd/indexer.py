@@ -87,7 +87,8 @@ class Indexer:
 
     def __init__(self, hashing, candidate_vectors_gpu, distance_func, compat=True, metric: Optional[str] = None,
                  seg_rows: int = 0, id_base: int = 0, algo: Optional[str] = None,
-                 row_ids: Optional[torch.Tensor] = None, schedule_stats: Optional[Tuple[float, float]] = None):
+                 row_ids: Optional[torch.Tensor] = None, schedule_stats: Optional[Tuple[float, float]] = None,
+                 corpus_keys: Optional[torch.Tensor] = None):
         self._hashing = hashing
         self._candidate_vectors_gpu = candidate_vectors_gpu
         self._distance_func = distance_func
@@ -103,6 +104,9 @@ class Indexer:
         # global row id of every local row (int32 [N], device) when the shard is not a contiguous range
         # (bucket-sharded corpus); default: id_base + local row
         self.row_ids = row_ids
+        # bucket key of every row (int32 [N], device) when the caller already has them (keys recorded by another run of
+        # the same hash: parity on an identical index); default: hash the corpus here (indexer.py:36-38)
+        self._given_keys = corpus_keys
         self._index2row = None
         self._perm_host = None
         self._e_sb = None
@@ -120,7 +124,13 @@ class Indexer:
         N, d = corpus.shape
         if corpus.dtype != torch.float32 or corpus.stride(1) != 1:
             corpus = corpus.float().contiguous()
-        keys, _ = self._hashing.hash_device(corpus, n=1)           # indexer.py:36-38: hash_times=1
+        if self._given_keys is not None:
+            keys = self._given_keys
+            if keys.shape != (N,) or keys.dtype != torch.int32 or keys.device != corpus.device:
+                raise ValueError("corpus_keys must be int32 [N] on the corpus device")
+            keys = keys.contiguous()
+        else:
+            keys, _ = self._hashing.hash_device(corpus, n=1)       # indexer.py:36-38: hash_times=1
         self.corpus_keys = keys.view(-1)
         self.perm, self.uniq_keys, self.offsets = build_csr_device(self.corpus_keys)
         self.n_buckets = int(self.uniq_keys.shape[0])
@@ -277,14 +287,20 @@ class Indexer:
             needed, overflow = status.cpu().tolist()
             if not overflow:
                 break
-            self._grow_task_table(tkey, needed)                     # segment table too small: grow and repeat
+            self._grow_task_table(tkey, needed, overflow)           # segment table too small: grow and repeat
         self.last_status = status
         self.last_algo = algo
         self._last_pack, self._last_tkey = pack, tkey
         return out_dist, out_idx, ncand, out_keys
 
-    def _grow_task_table(self, tkey, needed):
-        """status[1] != 0: the task table was too small; grow it, the caller repeats the call."""
+    def _grow_task_table(self, tkey, needed, flag=1):
+        """status[1] == 1: the task table was too small; grow it, the caller repeats the call.
+        status[1] == 2: the PLAN phase found the per-bucket counters at the head of the workspace non-zero on entry
+        (include/nlsh_hip.h, workspace contract): the batch got no tasks; drop the workspaces and fail loudly."""
+        if flag == 2:
+            self._ws.clear()
+            raise _capi.NlshHipError(_capi.E_WORKSPACE, "scan_topk(bucket-major): the pair counters at the head of the workspace "
+                                                        "were not zero on entry (workspace contract, include/nlsh_hip.h)")
         self._max_tasks[tkey] = int(needed * 1.25) + 1024
 
     def _scan_args(self, Q, d, keys, nkeys, k, algo, max_tasks, out_dist, out_idx, out_keys, ncand, status, ws):
@@ -370,7 +386,7 @@ class Indexer:
             needed, overflow = int(host[n - 2]), int(host[n - 1])
             if not overflow or Q == 0:
                 return (host[:Q * k].reshape(Q, k), host[Q * k:Q * k + Q], host[n:n + Q * P].reshape(Q, P), host[n + Q * P:n + nk])
-            self._grow_task_table(tkey, needed)
+            self._grow_task_table(tkey, needed, overflow)
 
     # `query()` on a large batch scans it in `query_chunks` row ranges on the stream and converts range c to Python lists while
     # the device scans range c+1: the conversion (0.45 ms per 10^4 queries) is as long as the scan, and a single range leaves
@@ -418,7 +434,7 @@ class Indexer:
                 needed, overflow = int(host[base + n - 2]), int(host[base + n - 1])
                 if not overflow or m == 0:
                     break
-                self._grow_task_table(tkey, needed)                 # task table too small for this range: grow, repeat it
+                self._grow_task_table(tkey, needed, overflow)       # task table too small for this range: grow, repeat it
                 inflight[c] = launch(c, lo, hi)
             a = host[base:base + n + m * P + m]
             yield (lo, hi, a[:m * k].reshape(m, k), a[m * k:m * k + m], a[n:n + m * P].reshape(m, P), a[n + m * P:n + m * P + m])
@@ -432,9 +448,11 @@ class Indexer:
     # the next FULL collection, like any long-lived object.  Because the counters restart from zero at every call, a tight
     # query loop would never reach the collector's thresholds for the older generations on its own: every
     # `_FULL_COLLECT_EVERY`-th promotion is followed by an explicit full collection (tens of ms in a torch process, so rare).
-    # Skipped when the application holds frozen objects of its own (gc.get_freeze_count() > 0), has the collector disabled, or
-    # sets this flag to False.
-    promote_results = True
+    # It rewrites the host application's collector generations, so it is OPT-IN (`Indexer.promote_results = True`; bench.py
+    # turns it on and says so in its JSON line, and reports the protocol number without it beside it): by default the
+    # conversion only pauses the collector for its own duration.  Even when on it is skipped when the application holds
+    # frozen objects of its own (gc.get_freeze_count() > 0) or has the collector disabled.
+    promote_results = False
     _FULL_COLLECT_EVERY = 2048
     _promotions = 0
 
@@ -512,6 +530,8 @@ class Indexer:
     def query_with_keys(self, query_vectors, key_lists: Sequence[Sequence[int]], k=10):
         """Scan stage on caller-supplied key lists (each in the iteration order the caller saw):
         parity on identical candidate sets, independent of hashing."""
+        # a query's keys are a set (nlsh/utils.pyx:27-31): a repeated key probes its bucket once; first-occurrence order kept
+        key_lists = [list(dict.fromkeys(int(key) for key in ks)) for ks in key_lists]
         Q = len(key_lists)
         P = max([len(ks) for ks in key_lists] + [1])
         tab = np.zeros((Q, P), dtype=np.int64)

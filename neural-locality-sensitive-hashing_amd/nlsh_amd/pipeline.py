@@ -147,5 +147,10 @@ class QueryPipeline:
         self.tail.synchronize()
 
     def overflowed(self) -> bool:
-        """True if any slot's last batch did not fit the task table (results incomplete: rebuild the pipeline)."""
-        return any(int(s.status.cpu()[1]) != 0 for s in self.slots)
+        """True if any slot's last batch did not fit the task table (results incomplete: rebuild the pipeline).
+        Raises if a slot's PLAN phase found its workspace head non-zero on entry (status 2: the batch got no tasks)."""
+        flags = [int(s.status.cpu()[1]) for s in self.slots]
+        if 2 in flags:
+            raise _capi.NlshHipError(_capi.E_WORKSPACE, "pipeline slot: the pair counters at the head of the workspace were not "
+                                                        "zero on entry (workspace contract, include/nlsh_hip.h)")
+        return any(flags)

@@ -14,7 +14,24 @@ G2_CASES = [
     ("sift_64_64_12", 128, (64, 64), 12, False, False, "sift_std"),
     ("two_layer_8", 128, (256, 256), 8, False, True, "sift_std"),
     ("glove25_96_8", 25, (96,), 8, False, False, "glove"),
+    # bias-free encoders (reference encoders.py:10,31 `with_bias=False`; the output layer keeps its bias, hashings.py:19)
+    ("two_layer_16_nobias", 128, (256, 256), 16, False, True, "sift_std"),
+    ("glove_64_64_12_nobias", 100, (64, 64), 12, False, False, "glove"),
 ]
+
+
+def g2_with_bias(name):
+    return not name.endswith("_nobias")
+
+
+def g2_weights(case):
+    """Seeded weights of a G2 case; encoder biases are None for the bias-free cases."""
+    name, d, hidden, H = case[0], case[1], case[2], case[3]
+    i = [c[0] for c in G2_CASES].index(name)
+    Ws, bs = synth.make_weights([d] + list(hidden) + [H], seed=100 + i)
+    if not g2_with_bias(name):
+        bs = [None] * (len(bs) - 1) + [bs[-1]]
+    return Ws, bs
 
 
 def g2_inputs(kind, d, n=96):

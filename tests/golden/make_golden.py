@@ -69,10 +69,12 @@ def set_weights(hashing, Ws, bs):
                 lin.bias.copy_(torch.from_numpy(b))
 
 
-def make_hashing(d, hidden, H, seed, tanh=False, two_layer=False):
-    enc = TwoLayer256Relu(d) if two_layer else MultiLayerRelu(d, list(hidden))
+def make_hashing(d, hidden, H, seed, tanh=False, two_layer=False, with_bias=True):
+    enc = TwoLayer256Relu(d, with_bias=with_bias) if two_layer else MultiLayerRelu(d, list(hidden), with_bias=with_bias)
     hashing = MultivariateBernoulli(enc, H, None, tanh_output=tanh)
     Ws, bs = synth.make_weights([d] + list(hidden) + [H], seed=seed)
+    if not with_bias:       # encoders.py:10,31: the encoder's Linear layers have no bias; the output layer keeps its own
+        bs = [None] * (len(bs) - 1) + [bs[-1]]
     set_weights(hashing, Ws, bs)
     hashing.train_mode(False)
     return hashing
@@ -118,7 +120,9 @@ g2_inputs = cases.g2_inputs
 def g2():
     arrays = {}
     for i, (name, d, hidden, H, tanh, two_layer, kind) in enumerate(G2_CASES):
-        hashing = make_hashing(d, hidden, H, seed=100 + i, tanh=tanh, two_layer=two_layer)
+        hashing = make_hashing(d, hidden, H, seed=100 + i, tanh=tanh, two_layer=two_layer, with_bias=cases.g2_with_bias(name))
+        if not cases.g2_with_bias(name):
+            assert all(m.bias is None for m in hashing._encoder.modules() if isinstance(m, torch.nn.Linear))
         x = g2_inputs(kind, d)
         xt = torch.from_numpy(x)
         with torch.no_grad():

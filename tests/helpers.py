@@ -14,7 +14,8 @@ _spec.loader.exec_module(cases)
 def make_hashing(d, hidden, H, Ws, bs, tanh=False, two_layer=False, compat=True, seed=0):
     from nlsh_amd.encoders import MultiLayerRelu, TwoLayer256Relu
     from nlsh_amd.hashings import MultivariateBernoulli
-    enc = TwoLayer256Relu(d) if two_layer else MultiLayerRelu(d, list(hidden))
+    with_bias = bs[0] is not None          # encoders.py:10,31: bias-free encoder layers (the output layer keeps its bias)
+    enc = TwoLayer256Relu(d, with_bias=with_bias) if two_layer else MultiLayerRelu(d, list(hidden), with_bias=with_bias)
     hashing = MultivariateBernoulli(enc, H, None, tanh_output=tanh, compat=compat, seed=seed)
     lin = [m for m in hashing._hasher.modules() if isinstance(m, torch.nn.Linear)]
     assert len(lin) == len(Ws)

@@ -270,3 +270,44 @@ def test_query_in_row_ranges_equals_the_single_range_call(compat):
             assert got[call][1] == answers[0][call][1]
             assert got[call][0] == answers[0][call][0]
     assert answers[0][0] != answers[0][1]                      # different probe draws per call: the comparison is not vacuous
+
+
+def test_hash_in_train_mode_uses_batch_statistics_like_the_reference():
+    """nlsh/hashings.py:66-67: `hash` runs `self._hasher(x)` in the module's CURRENT mode (nlsh/trainers/proposed.py:101-104
+    calls it in train mode).  With BatchNorm that means batch statistics + a running-statistics update; without BatchNorm
+    both modes are the same function and the fused kernel serves both."""
+    from nlsh_amd.encoders import MultiLayerRelu
+    from nlsh_amd.hashings import MultivariateBernoulli
+    torch.manual_seed(3)
+    d, H, B = 64, 12, 300
+    x = torch.randn(B, d, device="cuda") * 2 + 0.5
+    hashing = MultivariateBernoulli(MultiLayerRelu(d, [48, 32], with_batchnorm=True), H, None)
+    with torch.no_grad():
+        for m in hashing._hasher.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(); m.running_var.uniform_(0.5, 2.0); m.weight.uniform_(0.5, 1.5); m.bias.normal_()
+    hashing.train_mode(False)
+    eval_sets = hashing.hash(x, 1)
+    hashing.train_mode(True)
+    bn = [m for m in hashing._hasher.modules() if isinstance(m, torch.nn.BatchNorm1d)][0]
+    before = bn.running_mean.clone()
+    train_sets = hashing.hash(x, 1)
+    assert not torch.equal(bn.running_mean, before)                  # the train-mode forward updated the running statistics
+    with torch.no_grad():
+        probs = hashing._hasher(x)                                   # the same train-mode forward (batch statistics)
+    bits = (probs > 0.5).int().cpu().numpy()
+    want = oracle.pack_keys(bits[:, None, :], "ref_int16")[:, 0]
+    got = np.array([next(iter(s)) for s in train_sets])
+    assert all(len(s) == 1 for s in train_sets) and np.array_equal(got, want)
+    assert sum(a != b for a, b in zip(train_sets, eval_sets)) > B // 10     # and that is NOT the eval-mode (folded) function
+    # multi-probe in train mode: slot 0 is the hard key, rows past n_multi_rows stay single-probe, keys distinct per row
+    keys, nkeys = hashing.hash_device(x, n=6, n_multi_rows=256)
+    kh, nh = keys.cpu().numpy(), nkeys.cpu().numpy()
+    assert np.array_equal(kh[:, 0], want) and np.all(nh[256:] == 1) and nh[:256].max() > 1
+    assert all(len(set(kh[r, :nh[r]].tolist())) == nh[r] for r in range(B))
+    # an encoder without BatchNorm takes the fused kernel in either mode: identical keys
+    plain = MultivariateBernoulli(MultiLayerRelu(d, [48, 32]), H, None)
+    plain.train_mode(True)
+    a = plain.hash_device(x, n=1)[0].clone()
+    plain.train_mode(False)
+    assert torch.equal(a, plain.hash_device(x, n=1)[0])

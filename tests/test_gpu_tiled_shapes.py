@@ -1,0 +1,167 @@
+"""Every hand-scheduled task body of the LDS-tiled scan (csrc/scan_bucket.hip: l2_task<NW, NQ, NTL, METRIC>, NQ = queries
+a wave holds 0..4, NTL = 64-row tiles of the task 1..4, L2 and cosine = 40 bodies, plus the odd-chunk tail of l2_kblock and
+the fat-stage geometry of short segments) on a deterministic index: buckets of chosen sizes, each probed by a chosen
+number of queries, so that the task table provably holds every (queries, tiles) shape -- asserted from the table the PLAN
+phase left in the workspace -- and the results are held to the oracle (L2: bit-identical; cosine: <= 2e-5)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_lists_differ_only_at_ties, dev, make_hashing
+from nlsh_amd import _capi, synth
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+SIZES = (1, 40, 64, 65, 100, 128, 150, 192, 230, 256, 300, 513)     # rows per bucket: 1..4 tiles, 2- and 3-segment buckets
+GROUPS = tuple(range(1, 17)) + (17, 21, 33)                          # queries probing a bucket: every nq 1..16, and > 16 (several groups)
+Q = 64
+
+
+def _build(d, metric, seed):
+    """Corpus + per-row bucket keys + per-query key lists with every (size, group) combination present once."""
+    rng = np.random.default_rng(seed)
+    buckets = [(s, m) for s in SIZES for m in GROUPS]
+    N = sum(s for s, _ in buckets)
+    gen = synth.sift_like if metric == "l2" else synth.glove_like
+    corpus, queries = gen(N, d, seed=seed), gen(Q, d, seed=seed + 1)
+    corpus[N // 3:N // 3 + 30] = corpus[:30]                        # exact distance ties across buckets
+    keys = np.repeat(np.arange(len(buckets), dtype=np.int32) * 3 - 400, [s for s, _ in buckets])   # signed, gaps between keys
+    order = rng.permutation(N)                                      # rows of a bucket are scattered over the corpus
+    corpus_keys = np.empty(N, np.int32)
+    corpus_keys[order] = keys
+    key_lists = [[] for _ in range(Q)]
+    for b, (s, m) in enumerate(buckets):
+        for q in rng.choice(Q, size=m, replace=False):
+            key_lists[q].append(int(b * 3 - 400))
+    for q in range(Q):
+        rng.shuffle(key_lists[q])
+    key_lists[5].insert(2, 999999)                                  # an unknown key in the middle of a list
+    assert max(len(ks) for ks in key_lists) <= _capi.MAX_PROBES
+    return corpus, queries, corpus_keys, key_lists, buckets
+
+
+def _task_table(indexer, Qn, P, k, d):
+    """(nq, nrows) of every task the last tiled scan laid out, read from the workspace through the diagnostic layout call."""
+    L = _capi.lib()
+    tkey = indexer._last_tkey
+    max_tasks = indexer._max_tasks[tkey]
+    off_task, off_q = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    _capi.check(L.nlsh_scan_workspace_layout(Qn, P, k, max_tasks, indexer.n_buckets, d, _capi.SCAN_BUCKET_TILED,
+                                             ctypes.byref(off_task), ctypes.byref(off_q)))
+    ws = next(w for (stream, bm), w in indexer._ws.items() if bm)
+    n_tasks = int(indexer.last_status.cpu()[0])
+    tab = ws[off_task.value:off_task.value + 16 * n_tasks].view(torch.int32).view(-1, 4).cpu().numpy()
+    return tab[:, 1], tab[:, 3]
+
+
+@pytest.mark.parametrize("d", [128, 100, 96, 72])
+@pytest.mark.parametrize("metric", ["l2", "cosine"])
+def test_every_tiled_task_body_matches_the_oracle(metric, d):
+    from nlsh_amd.data import Glove, SIFT
+    from nlsh_amd.indexer import Indexer
+    k = 10
+    corpus, queries, corpus_keys, key_lists, buckets = _build(d, metric, seed=1000 + d)
+    Ws, bs = synth.make_weights([d, 32, 16], seed=d)
+    hashing = make_hashing(d, (32,), 16, Ws, bs, compat=False)     # the hash is not used: keys are injected on both sides
+    indexer = Indexer(hashing, dev(corpus), SIFT.distance if metric == "l2" else Glove.distance, compat=False, algo="tiled",
+                      corpus_keys=dev(corpus_keys))
+    res, nc, dist, idx = indexer.query_with_keys(dev(queries), key_lists, k=k)
+    assert indexer.last_algo == _capi.SCAN_BUCKET_TILED
+
+    # ---- the task table holds every (queries per wave 0..4) x (tiles 1..4) shape
+    P = max(len(ks) for ks in key_lists)
+    nq, nrows = _task_table(indexer, Q, P, k, d)
+    assert nq.min() >= 1 and nq.max() == 16 and nrows.min() >= 1 and nrows.max() == 256
+    shapes = set()
+    for a, r in zip(nq.tolist(), nrows.tolist()):
+        nt = (r + 63) // 64
+        for wave in range(4):                                       # queries are dealt round-robin over the 4 waves (NLSH_SLOT)
+            shapes.add((max(0, min(4, (a - wave + 3) // 4)), nt))
+    assert shapes == {(q_, t_) for q_ in range(5) for t_ in range(1, 5)}, sorted(shapes)
+    assert {(a, (r + 63) // 64) for a, r in zip(nq.tolist(), nrows.tolist())} >= {(a, t) for a in range(1, 17) for t in range(1, 5)}
+    # expected task count: per bucket ceil(m / 16) query groups x ceil(size / 256) segments
+    assert len(nq) == sum(((m + 15) // 16) * ((s + 255) // 256) for s, m in buckets)
+
+    # ---- results vs the oracle on the same candidate sets
+    perm, uniq, offs = oracle.build_csr(corpus_keys.astype(np.int64))
+    assert np.array_equal(indexer.perm.cpu().numpy(), perm)
+    qk, nk = oracle.keys_from_lists(key_lists)
+    od, oi, onc = oracle.query_batch(corpus, perm, uniq, offs, queries, qk, nk, k, metric)
+    assert nc == onc.tolist()
+    dist, idx = dist.cpu().numpy(), idx.cpu().numpy()
+    if metric == "l2":                                              # same k-ascending fmaf chain as the oracle: bit for bit
+        assert np.array_equal(idx, oi)
+        assert np.array_equal(dist.view(np.uint32), od.view(np.uint32))
+    else:
+        fin = np.isfinite(od)
+        assert np.array_equal(np.isfinite(dist), fin)
+        assert np.all(np.abs(dist[fin] - od[fin]) <= 2e-5 * np.maximum(1.0, np.abs(od[fin])))
+        for q in range(Q):
+            n = min(k, int(onc[q]))
+            assert_lists_differ_only_at_ties(idx[q][:n], oi[q][:n], queries[q], corpus, metric)
+            assert np.all(idx[q][n:] == -1)
+
+
+def test_repeated_probe_keys_probe_a_bucket_once():
+    """A query's keys are a set (nlsh/utils.pyx:27-31).  The facade de-duplicates caller-supplied lists; a raw key table
+    with repeats handed to the C ABI is de-duplicated by the plan kernels of every schedule: same result as the set."""
+    from nlsh_amd.data import SIFT
+    from nlsh_amd.indexer import Indexer
+    d, k = 128, 10
+    corpus, queries, corpus_keys, key_lists, _ = _build(d, "l2", seed=77)
+    Ws, bs = synth.make_weights([d, 32, 16], seed=1)
+    hashing = make_hashing(d, (32,), 16, Ws, bs, compat=False)
+    qd = dev(queries)
+    key_lists = [ks[:30] for ks in key_lists]                       # twice the keys must still fit one scan call (64 probes)
+    for algo in ("query", "bucket", "tiled"):
+        indexer = Indexer(hashing, dev(corpus), SIFT.distance, compat=False, algo=algo, corpus_keys=dev(corpus_keys))
+        base = indexer.query_with_keys(qd, key_lists, k=k)
+        doubled = [ks + ks[::-1] for ks in key_lists[:20]] + [ks[:1] * 3 + ks for ks in key_lists[20:]]
+        again = indexer.query_with_keys(qd, doubled, k=k)           # facade path: de-duplicated on the host, first occurrence kept
+        assert again[0] == base[0] and again[1] == base[1]
+        # raw table with repeats straight to nlsh_scan_topk (the facade is bypassed)
+        P = max(len(ks) for ks in key_lists)
+        tab = np.zeros((Q, 2 * P), np.int32)
+        cnt = np.zeros((Q,), np.int32)
+        for q, ks in enumerate(key_lists):
+            row = [kk for pair in zip(ks, ks) for kk in pair]       # every key twice, adjacent
+            tab[q, :len(row)] = np.asarray(row, np.int64).astype(np.int32)
+            cnt[q] = len(row)
+        dist, idx, ncand, _ = indexer.scan_tensors(qd, dev(tab), dev(cnt), k=k)
+        assert torch.equal(idx, base[3]) and torch.equal(dist, base[2]) and ncand.cpu().tolist() == base[1]
+
+
+@pytest.mark.parametrize("algo", ["bucket", "tiled"])
+def test_non_zero_workspace_head_is_detected_not_trusted(algo):
+    """Workspace contract of the bucket-major schedules (include/nlsh_hip.h): the per-bucket pair counters at the head of
+    the workspace must be zero on entry.  A violated contract is detected on the device (status[1] = 2, the batch gets no
+    task, nothing is addressed through a stale count) and surfaces as NLSH_E_WORKSPACE -- never a fault, never wrong ids."""
+    from nlsh_amd.data import SIFT
+    from nlsh_amd.indexer import Indexer
+    d, k = 128, 10
+    corpus, queries, corpus_keys, key_lists, _ = _build(d, "l2", seed=91)
+    Ws, bs = synth.make_weights([d, 32, 16], seed=1)
+    hashing = make_hashing(d, (32,), 16, Ws, bs, compat=False)
+    indexer = Indexer(hashing, dev(corpus), SIFT.distance, compat=False, algo=algo, corpus_keys=dev(corpus_keys))
+    qd = dev(queries)
+    good = indexer.query_with_keys(qd, key_lists, k=k)
+    for poison in ("ff", "plus3", "minus_plus"):
+        (wkey, ws), = [(kk, w) for kk, w in indexer._ws.items() if kk[1]]
+        head = ws[:4 * indexer.n_buckets].view(torch.int32)
+        assert int(head.abs().sum()) == 0                            # every completed call hands the counters back as zeros
+        if poison == "ff":
+            ws.fill_(0xFF)                                           # an uninitialised buffer
+        elif poison == "plus3":
+            head[7] = 3                                              # a stale count on one bucket
+        else:
+            head[3], head[11] = -2, 2                                # stale counts that cancel in the sum
+        with pytest.raises(_capi.NlshHipError) as err:
+            indexer.query_with_keys(qd, key_lists, k=k)
+        assert err.value.code == _capi.E_WORKSPACE
+        torch.cuda.synchronize()
+        assert not indexer._ws                                       # the poisoned buffers were dropped ...
+        again = indexer.query_with_keys(qd, key_lists, k=k)          # ... and the next call runs on a fresh zeroed one
+        assert again[0] == good[0] and again[1] == good[1] and torch.equal(again[3], good[3])

@@ -161,9 +161,10 @@ def test_bench_gpus_n_launches_n_ranks_or_fails(tmp_path):
 
 
 def test_result_lists_skip_the_young_generation_and_full_collections_still_happen():
-    """`Indexer._plain_lists`: the fresh lists are promoted past the collector's young generations (no collection is
-    triggered by them), the application's own frozen objects are respected, the flag turns it off, and cyclic garbage is
-    still reclaimed by the periodic full collection."""
+    """`Indexer._plain_lists` with the OPT-IN promotion on: the fresh lists are promoted past the collector's young
+    generations (no collection is triggered by them), the application's own frozen objects are respected, and cyclic
+    garbage is still reclaimed by the periodic full collection.  By default (flag off) the collector's generations are
+    left alone: only paused for the conversion itself."""
     import gc
     import weakref
     import numpy as np
@@ -171,24 +172,27 @@ def test_result_lists_skip_the_young_generation_and_full_collections_still_happe
     idx, nc = np.arange(20000, dtype=np.int32).reshape(2000, 10), np.full((2000,), 12, dtype=np.int32)
     seen = []
     cb = lambda phase, info: seen.append(info["generation"]) if phase == "start" else None   # noqa: E731
+    assert Indexer.promote_results is False          # a library call does not rewrite the application's GC state unasked
     gc.collect()
+    frozen0 = gc.get_freeze_count()
     gc.callbacks.append(cb)
+    Indexer.promote_results = True
     try:
         lists, counts = Indexer._plain_lists(idx, nc)
         probe = [[i] for i in range(50)]          # container allocations right after: would trip a young collection
         after, young = list(seen), gc.get_count()[0]
         assert after == [0] and young < 700 and probe    # only the explicit young pass BEFORE the conversion; none after
         assert lists == idx.tolist() and counts == nc.tolist()
-        old = Indexer.promote_results
         Indexer.promote_results = False
         try:
             del seen[:]
             lists2, counts2 = Indexer._plain_lists(idx, nc)     # (the first result stays alive: a freed one hands its count back)
+            assert gc.isenabled() and gc.get_freeze_count() == frozen0   # default: collector back on, nothing frozen or promoted
             probe = [[i] for i in range(50)]
             after = list(seen)
-            assert after and after[0] == 0 and lists2 == lists
+            assert after and after[0] == 0 and lists2 == lists  # the young collection the promotion avoids happens here
         finally:
-            Indexer.promote_results = old
+            Indexer.promote_results = True
         # an application that froze its own objects keeps them frozen
         gc.freeze()
         frozen = gc.get_freeze_count()
@@ -220,4 +224,5 @@ def test_result_lists_skip_the_young_generation_and_full_collections_still_happe
             Indexer._FULL_COLLECT_EVERY = old_every
         assert ref() is None
     finally:
+        Indexer.promote_results = False
         gc.callbacks.remove(cb)

@@ -39,8 +39,7 @@ def test_g1_int16_wrap_facts():
 def test_g2_hasher_forward(case):
     name, d, hidden, H, tanh, two_layer, kind = case
     g = np.load(os.path.join(G, "g2_hasher.npz"))
-    i = [c[0] for c in cases.G2_CASES].index(name)
-    Ws, bs = synth.make_weights([d] + list(hidden) + [H], seed=100 + i)
+    Ws, bs = cases.g2_weights(case)
     x = cases.g2_inputs(kind, d)
     z = oracle.mlp_forward(x, Ws, bs)
     z_ref = g[name + "/z"]

@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--recall-queries", type=int, default=1000)
     ap.add_argument("--shard", default="buckets", choices=["buckets", "rows"])
+    ap.add_argument("--save-hash", default="", help="write the trained hash as a portable .npz checkpoint (rank 0)")
+    ap.add_argument("--load-hash", default="", help="skip training: load a checkpoint written by --save-hash")
     args = ap.parse_args()
     import torch.distributed as dist
     from nlsh_amd import training
@@ -107,7 +109,11 @@ def main():
     # learned hash on a sample of rank 0's rows, broadcast (unit-norm rows: L2 ranking == cosine ranking; Deep1B uses L2)
     hashing = MultivariateBernoulli(MultiLayerRelu(d, [256, 256]), H, None, compat=H <= 16)
     t0 = time.time()
-    if rank == 0:
+    if args.load_hash:
+        from nlsh_amd import io
+        Ws_, bs_ = io.load_hasher_weights(args.load_hash)
+        training.load_weights(hashing, {**{f"W{i}": w for i, w in enumerate(Ws_)}, **{f"b{i}": b for i, b in enumerate(bs_)}})
+    elif rank == 0:
         sample = corpus[:: max(1, (hi - lo) // args.train_rows)][: args.train_rows].contiguous()
         knn = training.self_knn(sample, 10)
         training.fit_triplet(hashing, sample, knn, n_steps=args.train_steps, margin=1.0, log=lambda s: None)
@@ -117,6 +123,10 @@ def main():
             dist.broadcast(p_.data, src=0)
     hashing.train_mode(False)
     train_s = time.time() - t0
+    if args.save_hash and rank == 0:
+        os.makedirs(os.path.dirname(os.path.abspath(args.save_hash)), exist_ok=True)
+        np.savez_compressed(args.save_hash, meta=json.dumps(dict(vars(args), generator="tools/scale_deep100m.py deep_manifold_device seed 1234")),
+                            **training.export_weights(hashing))
 
     torch.cuda.synchronize()
     t0 = time.time()
@@ -188,6 +198,15 @@ def main():
             "scan_kernel": {0: "query-major", 1: "bucket-major", 2: "bucket-major LDS-tiled"}[pipe.algo],
             "rank0_scan_ms": scan_ms, "mean_candidates_per_query": sum_c / Q,
             "rank0_algorithmic_GBps": 4.0 * d * sum_c_local / (scan_ms * 1e-3) / 1e9,
+            # same accounting as bench.py: the bucket-major schedules fetch a row once per query group, fp32 VALU issue binds
+            # (3 flop per element: (q-c), +eps, fma; peak 157.3 TF); the query-major schedule re-reads rows per query (HBM, 8 TB/s)
+            "roofline": ({"bound": "hbm", "achieved": 4.0 * d * sum_c_local / (scan_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                          "frac": 4.0 * d * sum_c_local / (scan_ms * 1e-3) / 1e9 / 8000.0} if pipe.algo == 0 else
+                         {"bound": "valu", "achieved": 3.0 * d * sum_c_local / (scan_ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                          "frac": 3.0 * d * sum_c_local / (scan_ms * 1e-3) / 1e12 / 157.3}) | {
+                "kernel": {0: "scan_kernel", 1: "bscan2_kernel", 2: "bscan3_kernel"}[pipe.algo], "avg_launch_ms": scan_ms,
+                "sum_candidates_per_launch": sum_c_local, "algorithmic_bytes_per_launch": 4.0 * d * sum_c_local, "traffic": None,
+                "note": "scan kernel timed with HIP events inside the three-stage pipeline (shares the chip with the neighbouring batches' small kernels)"},
             "recall_at_10_on_sample": recall, "recall_sample": R, "properties": "ascending, distances vs torch on regenerated rows: ok",
             "rank0_peak_mem_gb": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
     if world > 1:
