@@ -64,6 +64,12 @@ extern "C" int nlsh_debug_scan_trace(float *host, int n_floats) {
 #ifndef NLSH_FAT_STAGES
 #define NLSH_FAT_STAGES 1
 #endif
+// 1: the tiled schedule stages its k-blocks by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write) into a
+// DOUBLE-buffered, XOR-swizzled tile, one barrier per k-block (l2_task_glds); 0: register staging into one padded tile, two
+// barriers per k-block (l2_task).  Same arithmetic in the same order: bit-identical results.
+#ifndef NLSH_TILED_GLDS
+#define NLSH_TILED_GLDS 0
+#endif
 
 #ifndef NLSH_TILED_MIN_WAVES
 #define NLSH_TILED_MIN_WAVES 1  // min waves per SIMD hint of the tiled kernel (8 = 64 VGPRs / 80 SGPRs: measured equal, 43 SGPR spills)
@@ -744,6 +750,7 @@ __device__ __forceinline__ void warm_query_lines_done(float &sink) {
 #endif
 }
 
+#if !NLSH_TILED_GLDS
 // All k-blocks of one L2 task for a wave that holds NQ (0..4) of its queries, NTL = tiles of the task (1..4): staging
 // (global -> registers -> LDS, next k-block's loads in flight during the current one) + the hand-scheduled k-blocks.
 // The (NQ, NTL) pair is chosen ONCE per task, outside the k-block loop: chosen per k-block, the 16 accumulators crossed
@@ -806,6 +813,179 @@ __device__ __forceinline__ void l2_task(float4 *tile, const float4 *corpus4, lon
     // released on EVERY path into the epilogue, whatever a future compiler makes of the loop.
     if (NQ > 0) warm_query_lines_done(qsink);
 }
+#endif  // !NLSH_TILED_GLDS
+
+#if NLSH_TILED_GLDS
+// ---- LDS-DMA staging (r03) ------------------------------------------------------------------------------------------------
+// The tile is an UNPADDED image of KBT 16-byte slots per row, two buffers of 256*KB slots.  A `global_load_lds_dwordx4` wave-
+// instruction writes 64 consecutive slots (wave-uniform base + lane * 16) while every lane supplies its own SOURCE address,
+// so the image is swizzled on the source side: slot p of row r holds chunk p ^ s(r), s(r) = (r >> (4 - log2 KBT)) & (KBT - 1).
+// Column reads (lane = row, ds_read_b128 is serviced in four groups of 16 lanes that are distinct mod 16, MI355X_MICROARCH.md
+// LDS table) then hit 16 distinct 16-byte bank groups: row stride 2^b slots contributes the low 4 - b bits of the row, the
+// swizzle the high b bits.  The 4 lanes that cover 64 contiguous bytes of a row still do (permuted): coalescing is unchanged.
+// s(r) only depends on the lane (r = tile * 64 + lane and only bits < 4 enter), so a lane's KBT slot offsets are constants of
+// the task: with the chunk loop fully unrolled a read costs no address arithmetic (tile offset = immediate, buffer = one XOR per
+// k-block and offset).
+// One k-block = { s_waitcnt vmcnt(0): my pieces of stage kb have landed; s_barrier: everybody's have, and everybody has finished
+// reading the other buffer; issue the DMA of stage kb + 1 into the other buffer; compute kb }.  RAW: the readers pass a barrier
+// after the issuing waves' vmcnt(0); WAR: the other buffer's last ds_read was retired (lgkmcnt(0) at the end of every k-block)
+// before the barrier that precedes its refill (cdna_hip_programming.md, "Read a staged buffer one phase AFTER the wait").
+template <int KBT>
+__device__ __forceinline__ constexpr int log2_kbt() { return KBT == 2 ? 1 : (KBT == 4 ? 2 : (KBT == 8 ? 3 : 4)); }
+
+__device__ __forceinline__ float4 lds_read16(const char *tile_bytes, unsigned off) {
+    return *reinterpret_cast<const float4 *>(tile_bytes + off);
+}
+
+// One k-block from LDS offsets `a[c]` (byte offset of this lane's slot of chunk c, tile 0, current buffer).  Blocks = (chunk,
+// tile) pairs in chunk-major order exactly like l2_kblock: row chunk of block j + 1 requested during block j, query chunk c + 1
+// requested during the first block of chunk c, prefetches past the end clamped.  FULL: nchunk == KBT, every index compile-time.
+template <int NQ, int NT, int KBT, int METRIC, bool FULL>
+__device__ __forceinline__ void kblock_glds(const char *tile_bytes, const unsigned (&a)[KBT], int nchunk, const const_f32p (&qk)[4], float (&acc)[4][4]) {
+    constexpr bool COS = METRIC == NLSH_METRIC_COSINE;
+    constexpr unsigned TSB = 64u * KBT * 16u;   // tile stride in bytes
+    QSet qa, qb;
+    float4 rr[2];
+    auto tile_block = [&](float (&ac)[4], const float4 r, const QSet &q) {
+        if (COS) cos_tile_block<NQ>(ac, r, q); else l2_tile_block<NQ>(ac, r, q);
+    };
+    if (FULL) {
+        rr[0] = lds_read16(tile_bytes, a[0]);
+        load_qset<NQ>(qa, qk, 0, 0.0f);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < KBT * NT; ++j) {
+            const int tl = j % NT, c = j / NT;
+            const int jn = (j + 1 < KBT * NT) ? j + 1 : j, tn = jn % NT, cn = jn / NT;   // the last block re-reads itself (value unused)
+            rr[(j + 1) & 1] = lds_read16(tile_bytes, a[cn] + tn * TSB);
+            if (tl == 0) {
+                const int cq = (c + 1 < KBT) ? c + 1 : c;
+                if ((c & 1) == 0) load_qset<NQ>(qb, qk, 16 * cq, rr[j & 1].x);
+                else load_qset<NQ>(qa, qk, 16 * cq, rr[j & 1].x);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            tile_block(acc[tl], rr[j & 1], (c & 1) ? qb : qa);
+            if (tl == NT - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the next chunk's queries (and first row chunk)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {   // the row's last, partial k-block (d / 4 not a multiple of KBT): one chunk at a time, slot offset computed at run time
+        for (int c = 0; c < nchunk; ++c) {
+            load_qset<NQ>(qa, qk, 16 * c, 0.0f);
+            const unsigned off = a[0] ^ ((unsigned)c << 4);   // a[c] = row base + ((c ^ s) << 4) = a[0] ^ (c << 4)
+            rr[0] = lds_read16(tile_bytes, off);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tl = 0; tl < NT; ++tl) {
+                if (tl + 1 < NT) rr[(tl + 1) & 1] = lds_read16(tile_bytes, off + (tl + 1) * TSB);
+                __builtin_amdgcn_sched_barrier(0);
+                tile_block(acc[tl], rr[tl & 1], qa);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+template <int NW, int NQ, int NTL, int METRIC = NLSH_METRIC_L2_EPS>
+__device__ __forceinline__ void l2_task(float4 *tile, const float4 *corpus4, long long stride4, int d4, int row0, int nrows,
+                                        const const_f32p (&qs)[4], int tid, int lane, float (&acc)[4][4],
+                                        [[maybe_unused]] unsigned long long (&tr)[3]) {
+    constexpr int KB = NLSH_TILED_KB;
+    static_assert(NW == 4 && (KB == 2 || KB == 4), "LDS-DMA staging: 256-thread workgroups, 2 or 4 chunks per k-block");
+    constexpr int kshift = NLSH_FAT_STAGES ? (NTL <= 1 ? 2 : (NTL == 2 ? 1 : 0)) : 0;
+    constexpr int KBT = KB << kshift, BK = log2_kbt<KBT>();
+    constexpr unsigned BUF = 256u * KB * 16u;            // bytes per buffer (a power of two: the buffer toggle is one XOR)
+    const int nkb = (d4 + KBT - 1) / KBT;
+    char *tile_bytes = reinterpret_cast<char *>(tile);
+    // ---- fill side: piece i of this thread is slot g = i * 256 + tid of the stage: row g >> BK, slot position g & (KBT - 1)
+    const int pos = tid & (KBT - 1);
+    const int sw_fill = ((tid >> BK) >> (4 - BK)) & (KBT - 1);     // s(row): the same for all of a thread's pieces (rows 256 >> BK apart)
+    const int cfill = pos ^ sw_fill;                               // chunk (within the k-block) this thread fetches
+    const float4 *rowp[KB];
+#pragma unroll
+    for (int i = 0; i < KB; ++i) rowp[i] = corpus4 + (long long)(row0 + min(((i * 256 + tid) >> BK), nrows - 1)) * stride4;
+    const int wave = tid >> 6;
+    // The DMA is issued from inline asm: through the builtin the compiler knows that LDS is being written asynchronously and puts an
+    // `s_waitcnt vmcnt(0)` in front of the next LDS read -- i.e. directly behind the issue, which serialises the stage with the
+    // k-block it was meant to run under (first build of this path: 0.31 ms against 0.276).  In asm the pieces are outside hipcc's
+    // bookkeeping; their completion is the explicit vmcnt(0) + barrier at the top of the next k-block.  M0 (LDS base of a piece)
+    // is written in the statement that uses it and restored (cdna_hip_programming.md, LDS-DMA recipe).
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)tile_bytes;   // LDS byte address of the tile
+    auto stage_dma = [&](int kb) {
+        const int gc = min(kb * KBT + cfill, d4 - 1);              // chunks past the row end are clamped (never evaluated)
+        const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds0 + (kb & 1) * BUF + wave * 1024u);
+        if (NLSH_ABLATE == 2) return;
+        unsigned keep;
+        if (KB == 4) {
+            const float4 *g0 = rowp[0] + gc, *g1 = rowp[1] + gc, *g2 = rowp[KB > 2 ? 2 : 0] + gc, *g3 = rowp[KB > 2 ? 3 : 0] + gc;
+            asm volatile("s_mov_b32 %[keep], m0\n\t"
+                         "s_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[g0], off\n\t"
+                         "s_add_u32 m0, %[d], 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[g1], off\n\t"
+                         "s_add_u32 m0, %[d], 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[g2], off\n\t"
+                         "s_add_u32 m0, %[d], 0x3000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[g3], off\n\t"
+                         "s_mov_b32 m0, %[keep]"
+                         : [keep] "=&s"(keep) : [d] "s"(dst0), [g0] "v"(g0), [g1] "v"(g1), [g2] "v"(g2), [g3] "v"(g3) : "memory", "scc");
+        } else {
+            const float4 *g0 = rowp[0] + gc, *g1 = rowp[1] + gc;
+            asm volatile("s_mov_b32 %[keep], m0\n\t"
+                         "s_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[g0], off\n\t"
+                         "s_add_u32 m0, %[d], 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[g1], off\n\t"
+                         "s_mov_b32 m0, %[keep]"
+                         : [keep] "=&s"(keep) : [d] "s"(dst0), [g0] "v"(g0), [g1] "v"(g1) : "memory", "scc");
+        }
+    };
+    // ---- read side: byte offsets of this lane's slots (tile 0, buffer 0)
+    const unsigned sw_read = ((unsigned)lane >> (4 - BK)) & (KBT - 1);
+    unsigned a[KBT];
+#pragma unroll
+    for (int c = 0; c < KBT; ++c) a[c] = (unsigned)lane * (KBT * 16u) + (((unsigned)c ^ sw_read) << 4);
+    stage_dma(0);
+    float qsink = 0.0f;
+    asm volatile("" : "+s"(qsink));
+    if (NQ > 0) warm_query_lines<(NQ > 0 ? NQ : 1)>(qs, 0, min(KBT, d4) * 16, qsink);
+    // full k-blocks in the loop (every index of their body is a compile-time constant), the row's last partial one -- if d / 4 is not a
+    // multiple of KBT -- once behind it: no branch between two forms of the body inside the loop
+    const int nkb_full = d4 / KBT;
+    auto kblock_head = [&](int kb) {
+        [[maybe_unused]] const unsigned long long ta = SCAN_NOW();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // my pieces of stage kb are in LDS
+        __builtin_amdgcn_s_barrier();                          // ... and everybody's; the other buffer is free
+        [[maybe_unused]] const unsigned long long tb = SCAN_NOW();
+        if (kb + 1 < nkb) stage_dma(kb + 1);
+        tr[0] += tb - ta;
+        tr[1] += SCAN_NOW() - tb;
+        if (NQ > 0) warm_query_lines_done(qsink);
+    };
+    for (int kb = 0; kb < nkb_full; ++kb) {
+        kblock_head(kb);
+        [[maybe_unused]] const unsigned long long tc = SCAN_NOW();
+        if (NQ > 0 && NLSH_ABLATE != 1 && NLSH_ABLATE != 6) {
+            const_f32p qk[4];
+#pragma unroll
+            for (int jq = 0; jq < 4; ++jq) qk[jq] = qs[jq] + kb * KBT * 4;
+            kblock_glds<(NQ > 0 ? NQ : 1), NTL, KBT, METRIC, true>(tile_bytes, a, KBT, qk, acc);
+            if (kb + 1 < nkb) warm_query_lines<(NQ > 0 ? NQ : 1)>(qs, (kb + 1) * KBT * 16, min((kb + 2) * KBT, d4) * 16, qsink);
+#ifdef NLSH_SCAN_TRACE
+            asm volatile("" : "+v"(acc[0][0]));
+            tr[2] += SCAN_NOW() - tc;
+#endif
+        }
+#pragma unroll
+        for (int c = 0; c < KBT; ++c) a[c] ^= BUF;             // the next k-block reads the other buffer
+    }
+    if (nkb_full < nkb) {
+        kblock_head(nkb_full);
+        if (NQ > 0 && NLSH_ABLATE != 1 && NLSH_ABLATE != 6) {
+            const_f32p qk[4];
+#pragma unroll
+            for (int jq = 0; jq < 4; ++jq) qk[jq] = qs[jq] + nkb_full * KBT * 4;
+            kblock_glds<(NQ > 0 ? NQ : 1), NTL, KBT, METRIC, false>(tile_bytes, a, d4 - nkb_full * KBT, qk, acc);
+        }
+    }
+    if (NQ > 0) warm_query_lines_done(qsink);
+}
+#endif  // NLSH_TILED_GLDS
 
 template <int NW, int NQ, int METRIC = NLSH_METRIC_L2_EPS>
 __device__ __forceinline__ void l2_task_nt(int ntile, float4 *tile, const float4 *corpus4, long long stride4, int d4, int row0, int nrows,
@@ -1038,7 +1218,12 @@ __global__ __launch_bounds__(64 * NW, NLSH_TILED_MIN_WAVES) void bscan3_kernel(B
     constexpr int ROWS = 64 * TPS;
     constexpr int SPT = ROWS * KB / NT;      // staged 16-byte words per thread and stage
     constexpr int RPP = NT / KB;             // rows covered by one pass of the workgroup
+#if NLSH_TILED_GLDS
+    __shared__ float4 tile[2 * ROWS * KB];   // two unpadded, swizzled buffers (LDS-DMA staging)
+    static_assert(NLSH_FAST_KBLOCK && NLSH_FAST_COSINE && QW == 4 && TPS == 4 && NW == 4, "LDS-DMA staging exists for the hand-scheduled task bodies only");
+#else
     __shared__ float4 tile[ROWS * RS];
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     [[maybe_unused]] const unsigned long long ts_entry = SCAN_NOW();
     if (NLSH_PRIO_OUT >= 0) __builtin_amdgcn_s_setprio(NLSH_PRIO_OUT);
