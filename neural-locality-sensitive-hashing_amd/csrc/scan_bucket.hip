@@ -472,6 +472,8 @@ __global__ __launch_bounds__(64) void bprep_kernel(BArgs a, int metric) {
     const int n = a.d4p * 4;
     if (metric == NLSH_METRIC_L2_EPS) {
         for (int e = lane; e < n; e += 64) dst[e] = e < a.d ? qp[e] : -1e-6f;  // (q - 0) + eps == 0 on padding
+    } else if (metric == NLSH_METRIC_L2_EPS_FOLDED) {
+        for (int e = lane; e < n; e += 64) dst[e] = e < a.d ? qp[e] + 1e-6f : 0.0f;   // eps folded into the query: (q + eps) - c; 0 - 0 on padding
     } else {
         float ss = 0.0f;
         for (int e = lane; e < a.d; e += 64) ss = fmaf(qp[e], qp[e], ss);
@@ -503,6 +505,9 @@ __device__ __forceinline__ void apply_qchunk(const QChunk<QW> &qc, const float4 
             if (METRIC == NLSH_METRIC_L2_EPS) {
                 // F.pairwise_distance: || (x1 - x2) + eps ||, summed in k order (nlsh/data.py:201)
                 const float t0 = (q0 - rv.x) + 1e-6f, t1 = (q1 - rv.y) + 1e-6f, t2 = (q2 - rv.z) + 1e-6f, t3 = (q3 - rv.w) + 1e-6f;
+                acc[jq] = fmaf(t3, t3, fmaf(t2, t2, fmaf(t1, t1, fmaf(t0, t0, acc[jq]))));
+            } else if (METRIC == NLSH_METRIC_L2_EPS_FOLDED) {
+                const float t0 = q0 - rv.x, t1 = q1 - rv.y, t2 = q2 - rv.z, t3 = q3 - rv.w;   // q already carries + eps (bprep)
                 acc[jq] = fmaf(t3, t3, fmaf(t2, t2, fmaf(t1, t1, fmaf(t0, t0, acc[jq]))));
             } else {
                 acc[jq] = fmaf(q3, rv.w, fmaf(q2, rv.z, fmaf(q1, rv.y, fmaf(q0, rv.x, acc[jq]))));
@@ -599,9 +604,33 @@ __device__ __forceinline__ void load_qset(QSet &q, const const_f32p (&qk)[4], in
     "v_add_f32 %[t2], 0x358637bd, %[t2]\n\tv_add_f32 %[t3], 0x358637bd, %[t3]\n\t"                                   \
     "v_fmac_f32 %[a" #J "], %[t0], %[t0]\n\tv_fmac_f32 %[a" #J "], %[t1], %[t1]\n\t"                                 \
     "v_fmac_f32 %[a" #J "], %[t2], %[t2]\n\tv_fmac_f32 %[a" #J "], %[t3], %[t3]\n\t"
+// The 2-op form (NLSH_METRIC_L2_EPS_FOLDED): eps is folded into the query copy bprep writes, a block is v_sub + v_fmac -- 8
+// instead of 12 VALU per chunk and query.  (q + eps) - c rounds differently from (q - c) + eps, so it is NOT the oracle's bits:
+// an opt-in within the north_star's 1e-4 tolerance, never the default.
+#define NLSH_QBLK2(J)                                                                                              \
+    "v_sub_f32 %[t0], %[q" #J "0], %[r0]\n\tv_sub_f32 %[t1], %[q" #J "1], %[r1]\n\t"                                 \
+    "v_sub_f32 %[t2], %[q" #J "2], %[r2]\n\tv_sub_f32 %[t3], %[q" #J "3], %[r3]\n\t"                                 \
+    "v_fmac_f32 %[a" #J "], %[t0], %[t0]\n\tv_fmac_f32 %[a" #J "], %[t1], %[t1]\n\t"                                 \
+    "v_fmac_f32 %[a" #J "], %[t2], %[t2]\n\tv_fmac_f32 %[a" #J "], %[t3], %[t3]\n\t"
 #define NLSH_QIN(J) [q##J##0] "s"(q.v[J].x), [q##J##1] "s"(q.v[J].y), [q##J##2] "s"(q.v[J].z), [q##J##3] "s"(q.v[J].w)
 #define NLSH_TMP [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
 #define NLSH_RIN [r0] "v"(r.x), [r1] "v"(r.y), [r2] "v"(r.z), [r3] "v"(r.w)
+template <int NQ>
+__device__ __forceinline__ void l2f_tile_block(float (&acc)[4], const float4 r, const QSet &q) {
+    float t0, t1, t2, t3;
+    if (NQ == 4)
+        asm volatile(NLSH_QBLK2(0) NLSH_QBLK2(1) NLSH_QBLK2(2) NLSH_QBLK2(3)
+                     : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), NLSH_TMP
+                     : NLSH_RIN, NLSH_QIN(0), NLSH_QIN(1), NLSH_QIN(2), NLSH_QIN(3));
+    else if (NQ == 3)
+        asm volatile(NLSH_QBLK2(0) NLSH_QBLK2(1) NLSH_QBLK2(2)
+                     : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), NLSH_TMP
+                     : NLSH_RIN, NLSH_QIN(0), NLSH_QIN(1), NLSH_QIN(2));
+    else if (NQ == 2)
+        asm volatile(NLSH_QBLK2(0) NLSH_QBLK2(1) : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), NLSH_TMP : NLSH_RIN, NLSH_QIN(0), NLSH_QIN(1));
+    else
+        asm volatile(NLSH_QBLK2(0) : [a0] "+v"(acc[0]), NLSH_TMP : NLSH_RIN, NLSH_QIN(0));
+}
 template <int NQ>
 __device__ __forceinline__ void l2_tile_block(float (&acc)[4], const float4 r, const QSet &q) {
     float t0, t1, t2, t3;
@@ -619,6 +648,7 @@ __device__ __forceinline__ void l2_tile_block(float (&acc)[4], const float4 r, c
         asm volatile(NLSH_QBLK(0) : [a0] "+v"(acc[0]), NLSH_TMP : NLSH_RIN, NLSH_QIN(0));
 }
 #undef NLSH_QBLK
+#undef NLSH_QBLK2
 #undef NLSH_QIN
 #undef NLSH_TMP
 
@@ -699,6 +729,8 @@ __device__ __forceinline__ void l2_kblock(const float4 *col, int RSt, int nchunk
                     if (tl == 0) copy_qset<NQ>(qv, cc ? qb : qa);   // this chunk's set was waited for behind the previous chunk's last block
                     cos_tile_block<NQ>(acc[tl], rr[j & 1], qv);
                 }
+            } else if (METRIC == NLSH_METRIC_L2_EPS_FOLDED) {
+                l2f_tile_block<NQ>(acc[tl], rr[j & 1], cc ? qb : qa);
             } else {
                 l2_tile_block<NQ>(acc[tl], rr[j & 1], cc ? qb : qa);
             }
@@ -718,6 +750,8 @@ __device__ __forceinline__ void l2_kblock(const float4 *col, int RSt, int nchunk
                     if (j == 0) copy_qset<NQ>(qv, qa);
                     cos_tile_block<NQ>(acc[j], rr[j & 1], qv);
                 }
+            } else if (METRIC == NLSH_METRIC_L2_EPS_FOLDED) {
+                l2f_tile_block<NQ>(acc[j], rr[j & 1], qa);
             } else {
                 l2_tile_block<NQ>(acc[j], rr[j & 1], qa);
             }
@@ -847,7 +881,9 @@ __device__ __forceinline__ void kblock_glds(const char *tile_bytes, const unsign
     QSet qa, qb;
     float4 rr[2];
     auto tile_block = [&](float (&ac)[4], const float4 r, const QSet &q) {
-        if (COS) cos_tile_block<NQ>(ac, r, q); else l2_tile_block<NQ>(ac, r, q);
+        if (COS) cos_tile_block<NQ>(ac, r, q);
+        else if (METRIC == NLSH_METRIC_L2_EPS_FOLDED) l2f_tile_block<NQ>(ac, r, q);
+        else l2_tile_block<NQ>(ac, r, q);
     };
     if (FULL) {
         rr[0] = lds_read16(tile_bytes, a[0]);
@@ -1081,7 +1117,7 @@ __device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, lo
         mygid[tl] = valid[tl] ? a.gid[prow] : -1;
         myinv[tl] = (METRIC == NLSH_METRIC_COSINE && valid[tl]) ? a.inv_norm[prow] : 0.0f;
     }
-    constexpr bool FAST = NLSH_FAST_KBLOCK && (METRIC == NLSH_METRIC_L2_EPS || NLSH_FAST_COSINE) && QW == 4 && TPS == 4;
+    constexpr bool FAST = NLSH_FAST_KBLOCK && (METRIC != NLSH_METRIC_COSINE || NLSH_FAST_COSINE) && QW == 4 && TPS == 4;
     [[maybe_unused]] unsigned long long trl[3] = {0, 0, 0};
     [[maybe_unused]] const unsigned long long ts_in = SCAN_NOW();
     if (FAST) {   // hand-scheduled form, specialised per (queries of this wave, tiles of the task); same barrier count on every path
@@ -1398,7 +1434,10 @@ int bucket_scan_run(const BucketScanCall &c) {
     a.P = c.P; a.k = c.k; a.seg = c.tiled ? 64 * TILED_TPS : c.seg; a.QB = c.tiled ? TILED_QB : (d4 <= 64 ? 8 : (d4 <= 128 ? 4 : 2));
     a.qpad_w = (float *)((char *)c.workspace + w.qpad); a.qpad = a.qpad_w; a.qpad_stride = (long long)d4 * 4; a.d4p = d4;
     // L2 with d % 4 == 0 needs neither padding nor normalisation: read the caller's queries directly
-    const bool prep = c.tiled && !(c.metric == NLSH_METRIC_L2_EPS && (c.d & 3) == 0 && (c.q_stride & 3) == 0 && ((uintptr_t)c.queries & 15) == 0);
+    // the folded L2 form exists in the tiled schedule only (it always needs the prepared query copy: q + eps); the other two
+    // schedules answer NLSH_METRIC_L2_EPS_FOLDED with the exact form, which is inside the same tolerance
+    const int metric = (!c.tiled && c.metric == NLSH_METRIC_L2_EPS_FOLDED) ? NLSH_METRIC_L2_EPS : c.metric;
+    const bool prep = c.tiled && !(metric == NLSH_METRIC_L2_EPS && (c.d & 3) == 0 && (c.q_stride & 3) == 0 && ((uintptr_t)c.queries & 15) == 0);
     if (c.tiled && !prep) { a.qpad = c.queries; a.qpad_stride = c.q_stride; }
     a.out_dist = c.out_dist; a.out_idx = c.out_idx; a.out_keys = c.out_keys; a.out_ncand = c.out_ncand; a.status = c.status;
     char *base = (char *)c.workspace;
@@ -1425,7 +1464,7 @@ int bucket_scan_run(const BucketScanCall &c) {
             hipLaunchKernelGGL(bscan_kernel, dim3(gb), dim3(256), 0, s, a, (int)gp);
         }
         hipLaunchKernelGGL(bscatter_kernel, dim3(gp), dim3(256), 0, s, a);
-        if (prep) hipLaunchKernelGGL(bprep_kernel, dim3((unsigned)c.Q), dim3(64), 0, s, a, c.metric);
+        if (prep) hipLaunchKernelGGL(bprep_kernel, dim3((unsigned)c.Q), dim3(64), 0, s, a, metric);
     }
     if ((c.phases & NLSH_PHASE_SCAN) && c.max_tasks > 0) {
         if (c.ev_begin) NLSH_CHECK_HIP(hipEventRecord((hipEvent_t)c.ev_begin, s));
@@ -1434,11 +1473,12 @@ int bucket_scan_run(const BucketScanCall &c) {
             // one workgroup per task; the chunked XCD map works on 8 x 16 ids.  (Persistent workgroups pulling tasks from a
             // per-XCD queue were measured three ways in r02 -- 0.447 / 0.423 / 0.350 ms against 0.283 ms: DESIGN.md 4.2.)
             const unsigned grid = (unsigned)((c.max_tasks + 127) / 128 * 128);
-            if (c.metric == NLSH_METRIC_L2_EPS) hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_L2_EPS, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
+            if (metric == NLSH_METRIC_L2_EPS) hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_L2_EPS, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
+            else if (metric == NLSH_METRIC_L2_EPS_FOLDED) hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_L2_EPS_FOLDED, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
             else hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_COSINE, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
         } else {
             const unsigned grid = (unsigned)((c.max_tasks + 3) / 4);  // one wavefront per task
-            if (c.metric == NLSH_METRIC_L2_EPS) launch_bscan2<NLSH_METRIC_L2_EPS>(a, d4, grid, s);
+            if (metric == NLSH_METRIC_L2_EPS) launch_bscan2<NLSH_METRIC_L2_EPS>(a, d4, grid, s);
             else launch_bscan2<NLSH_METRIC_COSINE>(a, d4, grid, s);
         }
         if (c.ev_end) NLSH_CHECK_HIP(hipEventRecord((hipEvent_t)c.ev_end, s));

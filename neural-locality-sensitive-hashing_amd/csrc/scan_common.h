@@ -261,7 +261,7 @@ __device__ __forceinline__ float row_partial(const float4 (&qv)[VPL], const bool
 
 template <int METRIC>
 __device__ __forceinline__ float finish_distance(float acc, float inv_norm) {
-    if (METRIC == NLSH_METRIC_L2_EPS) return sqrtf(acc);
+    if (METRIC != NLSH_METRIC_COSINE) return sqrtf(acc);   // both L2 forms
     return 1.0f - acc * inv_norm;  // 1 - cos (nlsh/data.py:109)
 }
 

@@ -297,7 +297,7 @@ extern "C" int nlsh_scan_topk_phase(const float *corpus_sorted, int64_t row_stri
     NLSH_REQUIRE(d >= 1 && d <= NLSH_MAX_DIM, NLSH_E_UNSUPPORTED, "scan_topk: d=%d not in [1,%d]", d, NLSH_MAX_DIM);
     NLSH_REQUIRE(k >= 1 && k <= NLSH_MAX_K, NLSH_E_UNSUPPORTED, "scan_topk: k=%d not in [1,%d]", k, NLSH_MAX_K);
     NLSH_REQUIRE(P >= 1 && P <= NLSH_MAX_PROBES, NLSH_E_UNSUPPORTED, "scan_topk: P=%d not in [1,%d]", P, NLSH_MAX_PROBES);
-    NLSH_REQUIRE(metric == NLSH_METRIC_L2_EPS || metric == NLSH_METRIC_COSINE, NLSH_E_INVALID, "scan_topk: metric=%d", metric);
+    NLSH_REQUIRE(metric == NLSH_METRIC_L2_EPS || metric == NLSH_METRIC_COSINE || metric == NLSH_METRIC_L2_EPS_FOLDED, NLSH_E_INVALID, "scan_topk: metric=%d", metric);
     NLSH_REQUIRE(algo == NLSH_SCAN_QUERY_MAJOR || algo == NLSH_SCAN_BUCKET_MAJOR || algo == NLSH_SCAN_BUCKET_TILED, NLSH_E_INVALID,
                  "scan_topk: algo=%d", algo);
     NLSH_REQUIRE(n_buckets >= 0 && max_tasks >= 0 && seg_rows >= 0, NLSH_E_INVALID, "scan_topk: negative size");
@@ -319,6 +319,7 @@ extern "C" int nlsh_scan_topk_phase(const float *corpus_sorted, int64_t row_stri
         return bucket_scan_run(c);
     }
 
+    if (metric == NLSH_METRIC_L2_EPS_FOLDED) metric = NLSH_METRIC_L2_EPS;   // the folded form exists in the tiled schedule only; the exact form is inside its tolerance
     ScanWs w;
     scan_layout(Q, P, k, max_tasks, &w);
     NLSH_REQUIRE(workspace_bytes >= w.total, NLSH_E_WORKSPACE, "scan_topk: workspace %zu < %zu", workspace_bytes, w.total);

@@ -14,7 +14,7 @@ CSRC = os.path.join(_PKG, "csrc")
 OK, E_INVALID, E_UNSUPPORTED, E_HIP, E_WORKSPACE = 0, -1, -2, -3, -4
 ACT_SIGMOID, ACT_TANH = 0, 1
 KEY_REF_INT16, KEY_FULL = 0, 1
-METRIC_L2_EPS, METRIC_COSINE = 0, 1
+METRIC_L2_EPS, METRIC_COSINE, METRIC_L2_EPS_FOLDED = 0, 1, 2
 SCAN_QUERY_MAJOR, SCAN_BUCKET_MAJOR, SCAN_BUCKET_TILED = 0, 1, 2
 MAX_LAYERS, MAX_HASH_BITS, MAX_PROBES, MAX_K, MAX_DIM, MAX_WIDTH = 8, 32, 64, 64, 1024, 632
 PHASE_PLAN, PHASE_SCAN, PHASE_MERGE = 1, 2, 4

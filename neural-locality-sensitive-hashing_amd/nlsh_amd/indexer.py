@@ -88,7 +88,7 @@ class Indexer:
     def __init__(self, hashing, candidate_vectors_gpu, distance_func, compat=True, metric: Optional[str] = None,
                  seg_rows: int = 0, id_base: int = 0, algo: Optional[str] = None,
                  row_ids: Optional[torch.Tensor] = None, schedule_stats: Optional[Tuple[float, float]] = None,
-                 corpus_keys: Optional[torch.Tensor] = None):
+                 corpus_keys: Optional[torch.Tensor] = None, l2_form: str = "exact"):
         self._hashing = hashing
         self._candidate_vectors_gpu = candidate_vectors_gpu
         self._distance_func = distance_func
@@ -107,6 +107,12 @@ class Indexer:
         # bucket key of every row (int32 [N], device) when the caller already has them (keys recorded by another run of
         # the same hash: parity on an identical index); default: hash the corpus here (indexer.py:36-38)
         self._given_keys = corpus_keys
+        # "exact" (default): sqrt(sum(((q - c) + 1e-6)^2)) in F.pairwise_distance's operation order, bit-identical to the oracle.
+        # "folded" (opt-in, NLSH_METRIC_L2_EPS_FOLDED): sqrt(sum(((q + 1e-6) - c)^2)) -- 2 instead of 3 vector operations per element in
+        # the LDS-tiled schedule, one rounding per element away from the reference's order (|d - d_exact| <= 1e-4 * max(1, d))
+        if l2_form not in ("exact", "folded"):
+            raise ValueError("l2_form must be 'exact' or 'folded'")
+        self.l2_form = l2_form
         self._index2row = None
         self._perm_host = None
         self._e_sb = None
@@ -308,7 +314,7 @@ class Indexer:
         (everything before `queries`, everything between `q_stride`/`Q` and the events).  Callers that launch many
         batches (nlsh_amd/pipeline.py) build them once per buffer set; a call is then one ctypes transition."""
         a = lambda t: None if t is None else t.data_ptr()   # noqa: E731
-        metric = _capi.METRIC_L2_EPS if self.metric == "l2" else _capi.METRIC_COSINE
+        metric = (_capi.METRIC_L2_EPS_FOLDED if self.l2_form == "folded" else _capi.METRIC_L2_EPS) if self.metric == "l2" else _capi.METRIC_COSINE
         pre = (a(self.corpus_sorted), self.row_stride, d, a(self.gid), a(self.uniq_keys), a(self.offsets), a(self.bucket_order),
                self.n_buckets, a(self.inv_norm))
         post = (Q, a(keys), a(nkeys), keys.shape[1], k, metric, algo, self.seg_rows or 512, a(out_dist), a(out_idx), a(out_keys),

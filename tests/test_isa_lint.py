@@ -58,7 +58,7 @@ def test_lint_allows_only_the_one_dword_warm_up_idiom():
 @needs_hipcc
 def test_shipped_tiled_scan_kernels_are_clean():
     rep = isa_lint.lint("scan_bucket.hip", "bscan3_kernel")
-    assert len(rep) == 2, sorted(rep)                      # L2 and cosine instantiations
+    assert len(rep) == 3, sorted(rep)                      # L2 (exact), L2 (folded eps, opt-in) and cosine instantiations
     for name, r in rep.items():
         assert r["scalar_loads"] > 100, name               # the hand-placed loads are really in there
         assert r["violations"] == [], (name, r["violations"][:5])

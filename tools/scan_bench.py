@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--queries", type=int, default=10_000)
     ap.add_argument("--tag", default="")
     ap.add_argument("--metric", default="", choices=["", "l2", "cosine"], help="override the workload's metric (sift1m with cosine = the same buckets and candidates through the cosine bodies)")
+    ap.add_argument("--l2-form", default="exact", choices=["exact", "folded"], help="folded: the opt-in 2-op L2 block (NLSH_METRIC_L2_EPS_FOLDED)")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--zeros", action="store_true", help="zero the grouped corpus and the queries after the index and the keys exist: same tasks and instruction stream, operands that toggle nothing (DVFS probe; pair with -DNLSH_ABLATE=5, ties change the selection)")
     ap.add_argument("--order", default="", choices=["", "pairs", "work", "density"], help="experiment: schedule order of the buckets recomputed on the host from THIS batch's keys (pairs: by (query, probe) pairs hitting the bucket; work: pairs x rows; density: full 16-query groups first, then by pairs), in place of the static size order")
@@ -52,7 +53,7 @@ def main():
     cg, qg = torch.from_numpy(corpus_h).cuda(), torch.from_numpy(queries_h).cuda()
     if args.metric:
         dist_fn = SIFT.distance if args.metric == "l2" else Glove.distance
-    ix = Indexer(hashing, cg, dist_fn, compat=compat, algo=args.algo)
+    ix = Indexer(hashing, cg, dist_fn, compat=compat, algo=args.algo, l2_form=args.l2_form)
     keys, nkeys = ix.hash_device(qg, hash_times=10, seed=7)
     if args.order:
         uk = ix.uniq_keys.cpu().numpy().astype(np.int64)
@@ -90,7 +91,7 @@ def main():
     torch.cuda.synchronize()
     step_ms = 1e3 * (time.perf_counter() - t0) / args.iters
     dist, idx, nc, _ = out
-    rec = {"tag": args.tag, "lib": os.path.basename(os.environ.get("NLSH_HIP_LIB", "default")), "algo": args.algo,
+    rec = {"tag": args.tag, "l2_form": args.l2_form, "lib": os.path.basename(os.environ.get("NLSH_HIP_LIB", "default")), "algo": args.algo,
            "scan_kernel_ms": float(kern.mean()), "scan_kernel_ms_min": float(kern.min()), "scan_phases_ms": scan_call_ms,
            "step_ms": step_ms, "tasks": int(ix.last_status.cpu()[0]), "max_tasks": ix._max_tasks[ix._last_tkey], "sum_candidates": int(nc.long().sum())}
     if os.environ.get("SCAN_BENCH_GROUPS"):   # pairs by the size of the query group they sit in (host recomputation from the keys)
