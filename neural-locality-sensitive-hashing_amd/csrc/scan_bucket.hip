@@ -70,6 +70,12 @@ extern "C" int nlsh_debug_scan_trace(float *host, int n_floats) {
 #ifndef NLSH_TILED_GLDS
 #define NLSH_TILED_GLDS 0
 #endif
+// Diagnostic timing builds only (WRONG results: the waves of a workgroup race on the tile): 1 = the stage barriers of the register-
+// staging task body are removed, which decouples the four waves of a workgroup -- what the barriers' straggler coupling costs.
+#ifndef NLSH_NO_STAGE_BARRIER
+#define NLSH_NO_STAGE_BARRIER 0
+#endif
+#define NLSH_STAGE_SYNC() do { if (!NLSH_NO_STAGE_BARRIER) __syncthreads(); } while (0)
 
 #ifndef NLSH_TILED_MIN_WAVES
 #define NLSH_TILED_MIN_WAVES 1  // min waves per SIMD hint of the tiled kernel (8 = 64 VGPRs / 80 SGPRs: measured equal, 43 SGPR spills)
@@ -817,11 +823,11 @@ __device__ __forceinline__ void l2_task(float4 *tile, const float4 *corpus4, lon
     if (NQ > 0) warm_query_lines<(NQ > 0 ? NQ : 1)>(qs, 0, min(KBt, d4) * 16, qsink);
     for (int kb = 0; kb < nkb; ++kb) {
         [[maybe_unused]] const unsigned long long ta = SCAN_NOW();
-        __syncthreads();  // everyone has finished reading the previous k-block
+        NLSH_STAGE_SYNC();  // everyone has finished reading the previous k-block
         [[maybe_unused]] const unsigned long long tb = SCAN_NOW();
 #pragma unroll
         for (int i = 0; i < SPT; ++i) tile[(sr + RPPt * i) * RSt + sc] = stg[i];
-        __syncthreads();
+        NLSH_STAGE_SYNC();
         if (kb + 1 < nkb) stage_load(kb + 1);  // in flight while this k-block is computed
         [[maybe_unused]] const unsigned long long tc = SCAN_NOW();
         tr[0] += tb - ta;   // first barrier: the slowest wave's previous k-block
@@ -1458,6 +1464,9 @@ int bucket_scan_run(const BucketScanCall &c) {
         // costs as much as a kernel boundary on this part.)  The per-bucket pair counters need no clearing launch: the
         // scatter step hands every count back, so they are zero again after every call (workspace contract, nlsh_hip.h).
         hipLaunchKernelGGL(bplan_kernel, dim3(gp), dim3(256), 0, s, a, stride);
+        // (r03: bcount + bscan as ONE single-workgroup launch for indexes of <= 8192 buckets -- strided bucket map, counts and prefixes
+        // through 64 KB of LDS, all loads of a thread's 8 buckets issued together -- took 23 us against 16.4 us for the two launches
+        // below (33 us before the loads were batched): one CU writes 12 k task descriptors slower than 23 workgroups do.)
         if (c.nb > 0) {
             const unsigned gb = (unsigned)((c.nb + 255) / 256);
             hipLaunchKernelGGL(bcount_kernel, dim3(gb), dim3(256), 0, s, a);
