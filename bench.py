@@ -249,6 +249,7 @@ def main():
     # rank r only builds the lists of its Q/N slice of the batch (`own_slice_qps`).
     def protocol_region(own, promote):
         Indexer.promote_results = promote
+        Indexer.defer_result_release = promote    # the two opt-in host-side behaviours of query() go together
 
         def query_lists(i):
             if sharded is not None:   # same seed on every rank
@@ -268,6 +269,7 @@ def main():
         fence()
         el = max_over_ranks(time.perf_counter() - t0)
         Indexer.promote_results = False
+        Indexer.defer_result_release = False
         return el, calls, held
 
     elapsed, call_s, (ids_api, nc_api) = protocol_region(own=False, promote=True)
@@ -478,8 +480,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "recall_at_10": recall,
             "value_protocol": "Indexer.query(batch, k, hash_times) -> Python lists of ALL Q queries on the calling rank, K synchronous calls "
-                              "(nlsh/trainers/base.py:93-96); Indexer.promote_results=True (opt-in GC promotion of the result lists, "
-                              "INTEGRATION.md)" + ("" if world == 1 else f"; sharded x{world}: every rank scans all queries over its shard, one "
+                              "(nlsh/trainers/base.py:93-96); Indexer.promote_results=True and Indexer.defer_result_release=True (the two opt-in host-side "
+                              "behaviours of query(): GC promotion of the result lists, release of the previous call's lists under the next call's scan; "
+                              "INTEGRATION.md; protocol_qps_default_gc has both off)" + ("" if world == 1 else f"; sharded x{world}: every rank scans all queries over its shard, one "
                                                     "all-gather + merge, every rank builds all Q lists"),
             "protocol_qps_default_gc": Q * steps / elapsed_default_gc,
             "own_slice_qps": None if elapsed_own is None else Q * steps / elapsed_own,

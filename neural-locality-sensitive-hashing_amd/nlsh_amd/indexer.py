@@ -387,6 +387,7 @@ class Indexer:
             if self.compat:
                 pin[n:n + Q * P].view(Q, P).copy_(keys, non_blocking=True)
                 pin[n + Q * P:n + nk].copy_(nkeys, non_blocking=True)
+            self._release_held()                                    # the device is busy now: free what an earlier call left with us
             torch.cuda.current_stream(q.device).synchronize()
             host = pin.numpy()
             needed, overflow = int(host[n - 2]), int(host[n - 1])
@@ -398,8 +399,16 @@ class Indexer:
     # the device scans range c+1: the conversion (0.45 ms per 10^4 queries) is as long as the scan, and a single range leaves
     # the host idle during the scan and the device idle during the conversion.  Results do not depend on the split (the hash
     # runs once over the whole batch; every query's candidates and top-k are its own; the schedule is the whole batch's).
-    query_chunks = 2
+    # None = automatic: 2 ranges, or 1 when `defer_result_release` is on -- the previous call's lists are then freed under the scan,
+    # the host is the longer side of the call whatever the split, and a second range only adds its launches (r03, 10^4 queries:
+    # 10.4 M queries/s with one range, 9.4 M with two, 7.6 M with three; with the release in the caller's loop 5.6 / 5.9 / 6.4 M).
+    query_chunks = None
     _CHUNK_MIN_ROWS = 2048
+
+    def _n_chunks(self):
+        if self.query_chunks is not None:
+            return int(self.query_chunks)
+        return 1 if self.defer_result_release else 2
 
     def _chunked_results(self, q, keys, nkeys, k, n_chunks):
         """Generator over row ranges of the batch: (lo, hi, ids [hi-lo, k], counts [hi-lo], keys, nkeys) as host arrays, each
@@ -430,6 +439,7 @@ class Indexer:
 
         for c, (lo, hi) in enumerate(bounds):
             inflight.append(launch(c, lo, hi))
+        self._release_held()                                        # the device is busy now: free what an earlier call left with us
         host = pin.numpy()
         for c, (lo, hi) in enumerate(bounds):
             m = hi - lo
@@ -459,6 +469,14 @@ class Indexer:
     # conversion only pauses the collector for its own duration.  Even when on it is skipped when the application holds
     # frozen objects of its own (gc.get_freeze_count() > 0) or has the collector disabled.
     promote_results = False
+    # A caller that loops `ids, counts = indexer.query(batch)` frees the previous call's 10^4 lists when it rebinds the names: ~0.3 ms
+    # of host time per 10^4 queries that sits between two calls, while the device idles.  OPT-IN (`Indexer.defer_result_release = True`):
+    # the indexer keeps a reference to its last TWO results and drops the older one right after the NEXT call has queued its device
+    # work -- the deallocation then runs under the scan instead of in front of it.  Results are unchanged and stay the caller's to keep;
+    # the cost is that up to two extra result sets (a few MB of Python objects each) stay alive per indexer.  Off by default for the
+    # same reason as `promote_results`: a library call should not change object lifetimes unasked.  bench.py turns both on for its
+    # headline region, says so, and reports the region with both off beside it.
+    defer_result_release = False
     _FULL_COLLECT_EVERY = 2048
     _promotions = 0
 
@@ -495,9 +513,25 @@ class Indexer:
                 results[qi] = [int(v) for v in idx_h[qi] if v >= 0]
         return results, counts
 
+    def _release_held(self):
+        """Drop all but the newest result kept by `defer_result_release` (called once the current call's device work is queued)."""
+        held = self.__dict__.get("_held")
+        if held:
+            del held[:-1]
+
+    def _keep(self, result):
+        if self.defer_result_release:
+            self.__dict__.setdefault("_held", []).append(result)
+        elif self.__dict__.get("_held"):
+            self._held = []
+        return result
+
     def query(self, query_vectors, k=10, hash_times=10, seed=None) -> Tuple[List[List[int]], List[int]]:
         """nlsh/indexer.py:56-96.  `seed` (not in the reference): the Philox seed of the multi-probe draws; None takes the next one
         from the hasher's call counter, like every other hashing call."""
+        return self._keep(self._query(query_vectors, k, hash_times, seed))
+
+    def _query(self, query_vectors, k, hash_times, seed):
         if self.metric not in ("l2", "cosine"):
             return self._query_generic(query_vectors, k, hash_times)
         q = self._as_queries(query_vectors)
@@ -506,9 +540,9 @@ class Indexer:
             _, idx, ncand, _ = self.scan_tensors(q, keys, nkeys, k=k)
             idx_h, nc_h = idx.cpu().numpy(), ncand.cpu().numpy()
             keys_h, nkeys_h = (keys.cpu().numpy(), nkeys.cpu().numpy()) if self.compat else (None, None)
-        elif self.query_chunks > 1 and q.shape[0] >= self.query_chunks * self._CHUNK_MIN_ROWS:
+        elif self._n_chunks() > 1 and q.shape[0] >= self._n_chunks() * self._CHUNK_MIN_ROWS:
             results, counts = [], []
-            for lo, hi, idx_h, nc_h, keys_h, nkeys_h in self._chunked_results(q, keys, nkeys, k, self.query_chunks):
+            for lo, hi, idx_h, nc_h, keys_h, nkeys_h in self._chunked_results(q, keys, nkeys, k, self._n_chunks()):
                 key_sets = {}
                 if self.compat:
                     for qi in np.nonzero(nc_h < k)[0].tolist():

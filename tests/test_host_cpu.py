@@ -226,3 +226,40 @@ def test_result_lists_skip_the_young_generation_and_full_collections_still_happe
     finally:
         Indexer.promote_results = False
         gc.callbacks.remove(cb)
+
+
+def test_deferred_result_release_is_opt_in_and_drops_the_older_result_under_the_next_call():
+    """`Indexer.defer_result_release`: off by default (a library call does not change object lifetimes unasked); when on, the
+    indexer holds its last two results and `_release_held()` -- called once the next call's device work is queued -- frees the
+    older one, i.e. the lists the caller stopped referencing when it rebound its names after the previous call."""
+    import weakref
+    from nlsh_amd.indexer import Indexer
+
+    class Lists(list):      # plain lists cannot be weak-referenced
+        pass
+
+    ix = Indexer.__new__(Indexer)
+    assert Indexer.defer_result_release is False
+    a = Lists([[1, 2]])
+    ra = weakref.ref(a)
+    assert ix._keep((a, [2]))[0] is a and not ix.__dict__.get("_held")
+    del a
+    assert ra() is None                                    # default: nothing is retained
+    Indexer.defer_result_release = True
+    try:
+        a, b = Lists([[1]]), Lists([[2]])
+        ra, rb = weakref.ref(a), weakref.ref(b)
+        ix._keep((a, [1]))                                 # call i returns; the caller holds `a`
+        ix._release_held()                                 # call i+1 queues its work: only the newest is kept, `a` is the newest
+        ix._keep((b, [1]))                                 # call i+1 returns; the caller rebinds: drops `a`, holds `b`
+        del a
+        assert ra() is not None                            # not freed in the caller's rebind ...
+        ix._release_held()                                 # ... but under call i+2's device work
+        assert ra() is None and rb() is not None
+        del b
+        assert rb() is not None
+        Indexer.defer_result_release = False
+        ix._keep(([], []))                                 # switching it off releases what was held
+        assert rb() is None
+    finally:
+        Indexer.defer_result_release = False
