@@ -111,7 +111,9 @@ def test_recall_matches_bench_claim(sift1m):
     from nlsh_amd.metrics import calculate_recall
     ix = sift1m["indexers"]["tiled"]
     gt = brute_force_topk(sift1m["qg"], sift1m["cg"], 10, "l2").cpu().numpy()
-    ids, nc = ix.query(sift1m["qg"], k=10, hash_times=10)
+    ids, nc = ix.query(sift1m["qg"], k=10, hash_times=10, seed=5000)      # bench.py's batch 0 with its fixed probe seed
     rec = calculate_recall(list(gt), ids, np.mean)
-    assert 0.70 < rec < 0.78, rec                       # bench.py reports 0.733 with its probe seed
-    assert 1500 < np.mean(nc) < 3500
+    # a seeded run: the bench line's own figures (BENCH_r02.json: recall@10 0.7355 at 2400.04 candidates per query); the slack is
+    # for ids that move between equidistant candidates, nothing else is free to change
+    assert abs(rec - 0.7355) <= 0.002, rec
+    assert abs(np.mean(nc) - 2400.04) <= 1.0, np.mean(nc)

@@ -1,15 +1,36 @@
+# End-of-round measurement set (run on the GPU box from the repo root through gpurun; results under gpurun_out/final/, the ones
+# to be judged are copied to profiles/ afterwards).  Needs lib/libnlsh_hip_trace.so for the clock pass:
+#   make -C neural-locality-sensitive-hashing_amd/csrc VARIANT=trace EXTRA="-DNLSH_SCAN_TRACE -DNLSH_SCAN_TRACE_CLOCK"
 set -e
 R=$PWD
-mkdir -p gpurun_out/final
-python -m pytest tests -m gpu -q -x 2>&1 | tail -2 > gpurun_out/final/tests.txt
-python bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err
+O=$R/gpurun_out/final
+mkdir -p $O
+python -m pytest tests -m gpu -q -x 2>&1 | tail -2 > $O/tests.txt
+python bench.py > $O/bench.json 2> $O/bench.err
+python bench.py --data clusters --no-cpu-baseline > $O/bench_clusters.json 2>/dev/null
+python bench.py --workload glove --no-cpu-baseline --pipeline on > $O/bench_glove.json 2>/dev/null
+python bench.py --workload glove --no-cpu-baseline --pipeline on --algo tiled > $O/bench_glove_tiled.json 2>/dev/null
+for w in 1 2 4 8; do python tools/shard_step_profile.py --world $w --rank 0 --steps 50; done 2>/dev/null > $O/shard_step_profile.jsonl
+if [ -f $R/neural-locality-sensitive-hashing_amd/lib/libnlsh_hip_trace.so ]; then
+  NLSH_HIP_LIB=$R/neural-locality-sensitive-hashing_amd/lib/libnlsh_hip_trace.so python tools/scan_clock.py > $O/scan_clock.txt 2>/dev/null || true
+fi
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --no-cpu-baseline --query-chunks 1 > $R/gpurun_out/final/bench_under_rocprof.json 2> /tmp/kt.err
-cp $(find /tmp/kt -name '*kernel_stats.csv' | head -1) $R/gpurun_out/final/kernel_stats.csv
-rm -rf /tmp/kt2 && rocprofv3 --kernel-trace --output-format csv -d /tmp/kt2 -- python3 $R/bench.py --no-cpu-baseline > /tmp/kt2.out 2> /tmp/kt2.err
-python3 $R/tools/kernel_trace_by_grid.py /tmp/kt2 bscan3 encode_hash bmerge bplan bscan_kernel bscatter bcount > $R/gpurun_out/final/kernel_trace_by_grid_default_command.csv
+# per-kernel statistics of the bench command (one row range per query() call: every scan launch has the full-batch grid)
+rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --no-cpu-baseline --query-chunks 1 > $O/bench_under_rocprof.json 2> /tmp/kt.err
+cp $(find /tmp/kt -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
+# counters of the same command (their own pass: no tracing domains beside --pmc)
 rm -rf /tmp/pm && rocprofv3 --pmc FETCH_SIZE SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/pm -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 --query-chunks 1 > /tmp/pm.out 2> /tmp/pm.err
-python3 $R/tools/pmc_summary.py /tmp/pm > $R/gpurun_out/final/pmc.json
+python3 $R/tools/pmc_summary.py /tmp/pm > $O/pmc.json
+# the cosine bodies of the tiled kernel: SIFT1M buckets scored by cosine (same tasks as the headline), statistics + counters
+rm -rf /tmp/ktc && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktc -- python3 $R/tools/scan_bench.py --metric cosine --no-check > $O/scan_bench_cosine.json 2> /tmp/ktc.err
+cp $(find /tmp/ktc -name '*kernel_stats.csv' | head -1) $O/cosine_kernel_stats.csv
+rm -rf /tmp/pmc && rocprofv3 --pmc FETCH_SIZE SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/pmc -- python3 $R/tools/scan_bench.py --metric cosine --no-check --iters 5 > /tmp/pmc.out 2> /tmp/pmc.err
+python3 $R/tools/pmc_summary.py /tmp/pmc bscan3 > $O/cosine_pmc.json
+# GloVe-shaped run through the tiled schedule: statistics
+rm -rf /tmp/ktg && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktg -- python3 $R/tools/scan_bench.py --workload glove --no-check > $O/scan_bench_glove_tiled.json 2> /tmp/ktg.err
+cp $(find /tmp/ktg -name '*kernel_stats.csv' | head -1) $O/glove_tiled_kernel_stats.csv
+# the opt-in folded L2 form: counters
+rm -rf /tmp/pmf && rocprofv3 --pmc FETCH_SIZE SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/pmf -- python3 $R/tools/scan_bench.py --l2-form folded --no-check --iters 5 > /tmp/pmf.out 2> /tmp/pmf.err
+python3 $R/tools/pmc_summary.py /tmp/pmf bscan3 > $O/folded_pmc.json
 cd $R
-python bench.py --workload glove --no-cpu-baseline --pipeline on > gpurun_out/final/bench_glove.json 2>/dev/null
-cat gpurun_out/final/tests.txt; cat gpurun_out/final/bench.json
+cat $O/tests.txt; cat $O/bench.json
