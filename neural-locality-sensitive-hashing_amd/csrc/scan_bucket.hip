@@ -72,6 +72,15 @@ extern "C" int nlsh_debug_scan_trace(float *host, int n_floats) {
 #endif
 // Diagnostic timing builds only (WRONG results: the waves of a workgroup race on the tile): 1 = the stage barriers of the register-
 // staging task body are removed, which decouples the four waves of a workgroup -- what the barriers' straggler coupling costs.
+// 1 (experiment, r03; OFF): in the tiled schedule the LAST partial list of a query to be written merges all of the query's lists right
+// there, inside the scan launch (a per-query countdown set up by the PLAN phase; lists travel through agent-scope stores and loads,
+// no fence), and the MERGE phase has nothing left to launch.  Correct -- the GPU suite and 600 repeated full-size scans without one
+// differing bit -- but it removes a 16-us kernel and makes the scan 36 us longer (0.269 -> 0.305 ms, profiles/r03_merge_in_scan_ab.txt):
+// every wave ends its task behind an `s_waitcnt vmcnt(0)` on write-through stores and a returning atomic, ~4 us of a 30-50 us task
+// during which its slot holds no work.  0 (shipped): bmerge_kernel.
+#ifndef NLSH_MERGE_IN_SCAN
+#define NLSH_MERGE_IN_SCAN 0
+#endif
 #ifndef NLSH_NO_STAGE_BARRIER
 #define NLSH_NO_STAGE_BARRIER 0
 #endif
@@ -129,6 +138,9 @@ struct BArgs {
     const int32_t *border;     // [nb] schedule order of the buckets (largest first) or nullptr = CSR order
     int32_t *btot;             // [3 * blocks of bscan] per-block (pairs, tasks, negative counters) totals
     int32_t *hits;             // [blocks of bplan] (query, probe) pairs each bplan block found a bucket for
+    int merge_in_scan;         // 1: tiled schedule with NLSH_MERGE_IN_SCAN (PLAN prefills the outputs and the countdowns, the scan merges)
+    int32_t *remaining;        // [Q] tiled schedule, NLSH_MERGE_IN_SCAN: partial lists of the query not yet written (bscatter adds a probe's
+                               // row segments, every finished list takes one off; whoever takes the last one merges the query)
     unsigned long long *tauq;  // [Q] running upper bound of each query's k-th best key (atomicMin), KEY_NONE-initialised
     const float *qpad;  // tiled variant: queries padded to d4p*4 floats (L2: pad = -eps; cosine: pre-normalised, pad = 0)
     float *qpad_w;      // same buffer, writable (bprep); qpad aliases `queries` when no padding/normalisation is needed
@@ -151,7 +163,18 @@ __global__ __launch_bounds__(256) void bplan_kernel(BArgs a, int stride) {
     if (idx < a.Q * a.P) {
         const long long q = idx / a.P;
         const int p = (int)(idx - q * a.P);
-        if (p == 0) a.tauq[q] = KEY_NONE;        // running bound of the query
+        if (p == 0) {
+            a.tauq[q] = KEY_NONE;        // running bound of the query
+            if (a.merge_in_scan) {        // the scan merges a query when its last list lands; a query without lists keeps this empty result
+                a.remaining[q] = 0;
+                a.out_ncand[q] = 0;
+                for (int e = 0; e < a.k; ++e) {
+                    a.out_dist[q * a.k + e] = __builtin_inff();
+                    a.out_idx[q * a.k + e] = -1;
+                    if (a.out_keys) a.out_keys[q * a.k + e] = KEY_NONE;
+                }
+            }
+        }
         int nk = a.nkeys[q];
         nk = nk < 0 ? 0 : (nk > a.P ? a.P : nk);
         if (p < nk) {
@@ -325,6 +348,7 @@ __global__ __launch_bounds__(256) void bscatter_kernel(BArgs a) {
     const int gi = rel / a.QB;
     const int t0 = a.taskoff[b] + gi, size = a.offsets[b + 1] - a.offsets[b], ng = a.bgroups[b];
     a.prec[idx] = make_int4(t0, rel - gi * a.QB, size, ng);
+    if (a.merge_in_scan) atomicAdd(&a.remaining[idx / a.P], (size + a.seg - 1) / a.seg);   // one partial list per row segment of this probe
     if (a.task_q) {
         // the tiled scan reads a task's query ids from the task's own record (address known from the task id alone: the
         // ids arrive with the descriptor instead of one dependent round trip later); one copy per row segment
@@ -1042,6 +1066,68 @@ __device__ __forceinline__ void l2_task_nt(int ntile, float4 *tile, const float4
     }
 }
 
+// Merge of ONE query's partial lists into its final top-k (one wavefront; `sc` = 64 u64 of LDS scratch owned by the wave).
+// AGENT: the lists were written inside the running launch by other workgroups (agent-scope stores, completed before the writer
+// took its count off the query's countdown): read them with agent-scope loads.
+template <bool AGENT>
+__device__ __forceinline__ void merge_query(const BArgs &a, long long q, int lane, uint64_t *sc) {
+    int nk = __builtin_amdgcn_readfirstlane(a.nkeys[q]);
+    nk = nk < 0 ? 0 : (nk > a.P ? a.P : nk);
+    // lane p holds probe p's record (written by bscatter): where its partial lists are
+    int ns_l = 0, j_l = 0, ng_l = 0;
+    long long t0_l = 0;
+    int size_l = 0;
+    if (lane < nk) {
+        const int4 rec = a.prec[q * a.P + lane];
+        t0_l = rec.x; j_l = rec.y; size_l = rec.z; ng_l = rec.w;
+        ns_l = (size_l + a.seg - 1) / a.seg;
+    }
+    {   // n_candidates of the query (indexer.py:71,94) = rows of its probed buckets
+        int c = size_l;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m);
+        if (lane == 0) a.out_ncand[q] = c;
+    }
+    // The query's partial lists (one per probe and row segment) are numbered 0..L-1 by an inclusive scan of the
+    // per-probe segment counts.  A round fetches 3 x R lists (R = 64/k per load instruction: lane -> (list, entry)) and
+    // SELECTS the k best of them and the best so far (merge_round); typical queries (<= 18 lists at k = 10) take one round.
+    int incl = ns_l;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const int up = __shfl_up(incl, m);
+        if (lane >= m) incl += up;
+    }
+    const int L = __builtin_amdgcn_readlane(incl, 63);
+    const int R = 64 / a.k;
+    const int r = lane / a.k, e = lane - r * a.k;
+    uint64_t carry = KEY_NONE;
+    for (int base = 0; base < L; base += 3 * R) {
+        uint64_t key[4];
+        key[0] = carry;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int li = base + s * R + r;
+            int lo = 0, hi = 63;  // probe of list li = first lane whose inclusive count exceeds li
+#pragma unroll
+            for (int step = 0; step < 6; ++step) {
+                const int mid = (lo + hi) >> 1;
+                if (__shfl(incl, mid) > li) hi = mid; else lo = mid + 1;
+            }
+            const int p = lo > 63 ? 63 : lo;
+            const int si = li - (__shfl(incl, p) - __shfl(ns_l, p));
+            const long long t = (long long)(((unsigned long long)(unsigned)__shfl((int)(t0_l >> 32), p) << 32) | (unsigned)__shfl((int)t0_l, p)) +
+                                (long long)si * __shfl(ng_l, p);
+            const int j = __shfl(j_l, p);
+            // t >= max_tasks: table overflow, status[1] was set by the scan kernel and the caller repeats the call
+            const bool live = r < R && li < L && t < a.max_tasks;
+            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.partial) + ((live ? t : 0) * a.QB + j) * a.k + e;
+            key[s + 1] = !live ? KEY_NONE : (AGENT ? (uint64_t)__hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint64_t)*src);
+        }
+        carry = merge_round<4>(key, a.k, lane, sc);
+    }
+    merge_finish(carry, a.k, lane, a.out_dist, a.out_idx, a.out_keys, q);
+}
+
 // QW queries per wave, NW waves per workgroup (QW*NW queries per task), TPS 64-row tiles per task.
 // k-blocks of KB chunks are the OUTER loop: one stage holds the KB-chunk slice of ALL 64*TPS rows of
 // the segment in LDS, so every scalar-loaded query chunk is applied to TPS row tiles (TPS x fewer
@@ -1051,7 +1137,7 @@ __device__ __forceinline__ void l2_task_nt(int ntile, float4 *tile, const float4
 // One task of the tiled schedule, start to finish (operands of the task already requested by the caller: descriptor and
 // the wave's query ids).  `tile` = the workgroup's LDS stage.
 template <int METRIC, int QW, int NW, int TPS>
-__device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, long long t, const int4 desc, const int (&qid_v)[QW], int tid, int lane,
+__device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, [[maybe_unused]] uint64_t *mscratch, long long t, const int4 desc, const int (&qid_v)[QW], int tid, int lane,
                                                 int wave, [[maybe_unused]] unsigned long long ts_entry) {
     constexpr int NT = 64 * NW;              // threads per workgroup
     constexpr int KB = NLSH_TILED_KB;        // 16-byte chunks per k-block
@@ -1230,11 +1316,36 @@ __device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, lo
             }
 #endif
             if (NLSH_ABLATE != 3) {
-                const uint64_t bound = select_k_smallest<TPS>(key, a.k, lane, out);
+                const uint64_t bound = select_k_smallest<TPS, false, NLSH_MERGE_IN_SCAN != 0>(key, a.k, lane, out);
                 if (bound != KEY_NONE && lane == 0) atomicMin(a.tauq + qid[jq], (unsigned long long)bound);
             } else if (lane < a.k) out[lane] = key[0];
         }
     }
+#if NLSH_MERGE_IN_SCAN
+    // The wave's lists are on their way to memory (agent-scope stores).  Once they are acknowledged, each takes one off its query's
+    // countdown; the list that takes the LAST one merges the query here and now (every other list of the query was acknowledged
+    // before its writer decremented, and is read with agent-scope loads): the merged result does not depend on who merges.
+    if (NLSH_ABLATE != 3) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int left[QW];
+#pragma unroll
+        for (int jq = 0; jq < QW; ++jq) {
+            left[jq] = 0;
+            if (jq < nqw && lane == 0) left[jq] = __hip_atomic_fetch_add(a.remaining + qid[jq], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        int last = 0;
+#pragma unroll
+        for (int jq = 0; jq < QW; ++jq) last |= (jq < nqw && __builtin_amdgcn_readfirstlane(left[jq]) == 1) ? (1 << jq) : 0;
+        if (last) {
+#pragma nounroll
+            for (int jq = 0; jq < QW; ++jq) {
+                if (!((last >> jq) & 1)) continue;
+                const int qm = jq == 0 ? qid[0] : (jq == 1 ? qid[1] : (jq == 2 ? qid[2] : qid[QW - 1]));
+                merge_query<true>(a, qm, lane, mscratch + wave * 64);
+            }
+        }
+    }
+#endif
 #ifdef NLSH_SCAN_TRACE
     if (tid == 0 && t < NLSH_TRACE_SLOTS) {
         const unsigned long long ts4 = SCAN_NOW();
@@ -1296,7 +1407,15 @@ __global__ __launch_bounds__(64 * NW, NLSH_TILED_MIN_WAVES) void bscan3_kernel(B
     if (NLSH_ABLATE == 9) return;   // diagnostic: every workgroup leaves after its descriptor loads (what dispatching the grid costs)
     if (NLSH_ABLATE == 8 && desc.y <= NLSH_ABLATE_NQ) return;   // diagnostic: tasks with few queries vanish (what the low-density tasks cost)
     if (NLSH_ABLATE == 7 && desc.w <= 64) return;   // diagnostic: tasks of <= 64 rows vanish (what a kernel without the tail of tiny tasks would take)
-    tiled_task_body<METRIC, QW, NW, TPS>(a, tile, t, desc, qid_v, tid, lane, wave, ts_entry);
+#if NLSH_MERGE_IN_SCAN
+    __shared__ uint64_t mscratch[NW * 64];   // per-wave scratch of the in-scan merge (the tile may still be read by slower waves)
+    // the workspace-contract check bmerge_kernel carries otherwise (see there): every pair counter is back at zero after the scatter
+    for (long long b = (long long)blockIdx.x * NT + tid; b < a.nb; b += (long long)gridDim.x * NT)
+        if (a.bcount[b] != 0) a.status[1] = 2;
+#else
+    uint64_t *mscratch = nullptr;
+#endif
+    tiled_task_body<METRIC, QW, NW, TPS>(a, tile, mscratch, t, desc, qid_v, tid, lane, wave, ts_entry);
 }
 
 __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
@@ -1304,67 +1423,14 @@ __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
     // contract).  The PLAN phase's sum check catches stale counts that change the totals (those would overrun the pair
     // lists); this per-bucket check catches the rest (stale counts that cancel in the sum mis-size individual lists: every
     // access stays in bounds -- clamped query ids, guarded slots -- but the lists are wrong), so a violated contract is
-    // ALWAYS reported (status[1] = 2), never a silently wrong result.
+    // ALWAYS reported (status[1] = 2), never a silently wrong result.  (With NLSH_MERGE_IN_SCAN the tiled scan does this check.)
     for (long long b = (long long)blockIdx.x * 256 + threadIdx.x; b < a.nb; b += (long long)gridDim.x * 256)
         if (a.bcount[b] != 0) a.status[1] = 2;
     const int lane = threadIdx.x & 63;
     const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= a.Q) return;
-    int nk = __builtin_amdgcn_readfirstlane(a.nkeys[q]);
-    nk = nk < 0 ? 0 : (nk > a.P ? a.P : nk);
-    // lane p holds probe p's record (written by bscatter): where its partial lists are
-    int ns_l = 0, j_l = 0, ng_l = 0;
-    long long t0_l = 0;
-    int size_l = 0;
-    if (lane < nk) {
-        const int4 rec = a.prec[q * a.P + lane];
-        t0_l = rec.x; j_l = rec.y; size_l = rec.z; ng_l = rec.w;
-        ns_l = (size_l + a.seg - 1) / a.seg;
-    }
-    {   // n_candidates of the query (indexer.py:71,94) = rows of its probed buckets
-        int c = size_l;
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m);
-        if (lane == 0) a.out_ncand[q] = c;
-    }
-    // The query's partial lists (one per probe and row segment) are numbered 0..L-1 by an inclusive scan of the
-    // per-probe segment counts.  A round fetches 3 x R lists (R = 64/k per load instruction: lane -> (list, entry)) and
-    // SELECTS the k best of them and the best so far (merge_round); typical queries (<= 18 lists at k = 10) take one round.
-    int incl = ns_l;
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const int up = __shfl_up(incl, m);
-        if (lane >= m) incl += up;
-    }
-    const int L = __builtin_amdgcn_readlane(incl, 63);
-    const int R = 64 / a.k;
-    const int r = lane / a.k, e = lane - r * a.k;
     __shared__ uint64_t scratch[4][64];
-    uint64_t *sc = scratch[threadIdx.x >> 6];
-    uint64_t carry = KEY_NONE;
-    for (int base = 0; base < L; base += 3 * R) {
-        uint64_t key[4];
-        key[0] = carry;
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const int li = base + s * R + r;
-            int lo = 0, hi = 63;  // probe of list li = first lane whose inclusive count exceeds li
-#pragma unroll
-            for (int step = 0; step < 6; ++step) {
-                const int mid = (lo + hi) >> 1;
-                if (__shfl(incl, mid) > li) hi = mid; else lo = mid + 1;
-            }
-            const int p = lo > 63 ? 63 : lo;
-            const int si = li - (__shfl(incl, p) - __shfl(ns_l, p));
-            const long long t = (long long)(((unsigned long long)(unsigned)__shfl((int)(t0_l >> 32), p) << 32) | (unsigned)__shfl((int)t0_l, p)) +
-                                (long long)si * __shfl(ng_l, p);
-            const int j = __shfl(j_l, p);
-            // t >= max_tasks: table overflow, status[1] was set by the scan kernel and the caller repeats the call
-            key[s + 1] = (r < R && li < L && t < a.max_tasks) ? a.partial[(t * a.QB + j) * a.k + e] : KEY_NONE;
-        }
-        carry = merge_round<4>(key, a.k, lane, sc);
-    }
-    merge_finish(carry, a.k, lane, a.out_dist, a.out_idx, a.out_keys, q);
+    merge_query<false>(a, q, lane, scratch[threadIdx.x >> 6]);
 }
 
 #ifndef NLSH_TILED_QB
@@ -1377,7 +1443,7 @@ constexpr int TILED_QB = NLSH_TILED_QB;  // queries per task of the tiled schedu
 constexpr int TILED_TPS = NLSH_TILED_TPS;  // 64-row tiles per task of the tiled schedule (segment = 64*TPS rows)
 
 struct BWs {
-    size_t pbkt, prec, inv_q, bcount, pairoff, taskoff, bgroups, counters, btot, hits, task, task_q, partial, qpad, tauq, total;
+    size_t pbkt, prec, inv_q, bcount, pairoff, taskoff, bgroups, counters, btot, hits, remaining, task, task_q, partial, qpad, tauq, total;
 };
 static void blayout(long long Q, int P, int k, long long max_tasks, long long nb, int d, bool tiled, BWs *w) {
     size_t o = 0;
@@ -1392,6 +1458,7 @@ static void blayout(long long Q, int P, int k, long long max_tasks, long long nb
     w->counters = o; o += ws_align(64);
     w->btot = o;     o += ws_align((size_t)((nb + 255) / 256 + 1) * 12);
     w->hits = o;     o += ws_align((size_t)((Q * P + 255) / 256 + 1) * 4);
+    w->remaining = o; o += ws_align((size_t)(Q > 0 ? Q : 1) * 4);
     w->task = o;     o += ws_align((size_t)max_tasks * sizeof(int4));
     w->task_q = o;   o += tiled ? ws_align((size_t)max_tasks * TILED_QB * 4) : 0;
     w->partial = o;  o += ws_align((size_t)max_tasks * (tiled ? TILED_QB : 8) * k * 8);
@@ -1451,7 +1518,7 @@ int bucket_scan_run(const BucketScanCall &c) {
     char *base = (char *)c.workspace;
     a.pbkt = (int32_t *)(base + w.pbkt); a.prec = (int4 *)(base + w.prec); a.inv_q = (int32_t *)(base + w.inv_q);
     a.bcount = (int32_t *)(base + w.bcount); a.pairoff = (int32_t *)(base + w.pairoff); a.taskoff = (int32_t *)(base + w.taskoff); a.bgroups = (int32_t *)(base + w.bgroups);
-    a.counters = (int32_t *)(base + w.counters); a.btot = (int32_t *)(base + w.btot); a.hits = (int32_t *)(base + w.hits); a.border = c.bucket_order; a.task = (int4 *)(base + w.task); a.task_q = c.tiled ? (int32_t *)(base + w.task_q) : nullptr; a.partial = (uint64_t *)(base + w.partial);
+    a.counters = (int32_t *)(base + w.counters); a.btot = (int32_t *)(base + w.btot); a.hits = (int32_t *)(base + w.hits); a.remaining = (int32_t *)(base + w.remaining); a.merge_in_scan = (c.tiled && NLSH_MERGE_IN_SCAN) ? 1 : 0; a.border = c.bucket_order; a.task = (int4 *)(base + w.task); a.task_q = c.tiled ? (int32_t *)(base + w.task_q) : nullptr; a.partial = (uint64_t *)(base + w.partial);
     a.max_tasks = c.max_tasks;
     a.tauq = (unsigned long long *)(base + w.tauq);
 
@@ -1494,7 +1561,8 @@ int bucket_scan_run(const BucketScanCall &c) {
         }
         if (c.ev_end) NLSH_CHECK_HIP(hipEventRecord((hipEvent_t)c.ev_end, s));
     }
-    if (c.phases & NLSH_PHASE_MERGE) hipLaunchKernelGGL(bmerge_kernel, dim3((unsigned)((c.Q + 3) / 4)), dim3(256), 0, s, a);
+    // (the tiled schedule with NLSH_MERGE_IN_SCAN has merged every query inside its scan launch: nothing to do here)
+    if ((c.phases & NLSH_PHASE_MERGE) && !a.merge_in_scan) hipLaunchKernelGGL(bmerge_kernel, dim3((unsigned)((c.Q + 3) / 4)), dim3(256), 0, s, a);
     NLSH_CHECK_HIP(hipGetLastError());
     return NLSH_OK;
 }

@@ -111,7 +111,9 @@ __device__ __forceinline__ uint32_t wave_minmax_u32(uint32_t x) {
 // CLAMP (the merges): keys that reach a merge are distinct when every (query, bucket) pair was scanned once -- the plan
 // kernels de-duplicate a query's probe keys, corpus shards are disjoint -- but nlsh_merge_topk takes whatever lists a C
 // caller hands it: with repeated keys the tie search can select more than k, so the compaction never writes past out[k).
-template <int NK, bool CLAMP = false>
+// AGENT (the tiled scan's partial lists when the query's last list merges them inside the same launch, NLSH_MERGE_IN_SCAN): the k
+// survivors are written with agent-scope stores (sc1: written through, visible to the other XCDs' sc1 loads once acknowledged).
+template <int NK, bool CLAMP = false, bool AGENT = false>
 __device__ __forceinline__ uint64_t select_k_smallest(const uint64_t (&key)[NK], int k, int lane, uint64_t *out) {
     uint32_t hi[NK], lo[NK];
     int n = 0;
@@ -170,10 +172,16 @@ __device__ __forceinline__ uint64_t select_k_smallest(const uint64_t (&key)[NK],
         const bool sel = key[i] != KEY_NONE && (hi[i] < dk || (hi[i] == dk && lo[i] <= idk));
         const unsigned long long m = __ballot(sel);
         const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (sel && (!CLAMP || pos < k)) out[pos] = key[i];
+        if (sel && (!CLAMP || pos < k)) {
+            if (AGENT) __hip_atomic_store(reinterpret_cast<unsigned long long *>(out) + pos, (unsigned long long)key[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else out[pos] = key[i];
+        }
         base += __popcll(m);
     }
-    if (lane >= base && lane < k) out[lane] = KEY_NONE;
+    if (lane >= base && lane < k) {
+        if (AGENT) __hip_atomic_store(reinterpret_cast<unsigned long long *>(out) + lane, (unsigned long long)KEY_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else out[lane] = KEY_NONE;
+    }
     return n >= k ? ((uint64_t)dk + 1ull) << 32 : KEY_NONE;
 }
 

@@ -183,8 +183,33 @@ def inflight_violations(lines):
     return report
 
 
+def spills_in_hot_loops(lines, hot="v_fmac_f32"):
+    """SGPR spill traffic (v_writelane_b32, or a v_readlane_b32 of a constant lane into an SGPR: the compiler's spill / reload
+    forms) inside any loop whose body holds the distance arithmetic.  Loop = a backward branch to a label; body = the lines between.
+    Spills elsewhere (kernel arguments parked in a VGPR at the prologue, reloaded in the epilogue) cost nothing that matters."""
+    pos = {}
+    for i, s_ in enumerate(lines):
+        m = _LABEL.match(s_)
+        if m:
+            pos[m.group(1)] = i
+    # the VGPRs the compiler spills SGPRs into = the destinations of the function's v_writelane_b32 (a v_readlane of a constant
+    # lane from any other VGPR is ordinary code: wave reductions read lane 63)
+    spill_vgprs = {x.split()[1].rstrip(",") for x in lines if x.startswith("v_writelane_b32")}
+    bad = []
+    for i, s_ in enumerate(lines):
+        m = _BRANCH.match(s_)
+        if m and m.group(2) in pos and pos[m.group(2)] < i:
+            body = lines[pos[m.group(2)]:i]
+            if any(x.startswith(hot) for x in body):
+                for x in body:
+                    r = re.match(r"^v_readlane_b32 s\d+, (v\d+), \d+$", x)
+                    if x.startswith("v_writelane_b32") or (r and r.group(1) in spill_vgprs):
+                        bad.append(x)
+    return bad
+
+
 def lint(src="scan_bucket.hip", match="bscan3_kernel", extra=()):
-    """-> {kernel: {"resources": {...}, "violations": [...], "scalar_loads": n, "writelanes": n}}"""
+    """-> {kernel: {"resources": {...}, "violations": [...], "scalar_loads": n, "writelanes": n, "hot_loop_spills": [...]}}"""
     asm, remarks = compile_asm(src, extra)
     res = resources(remarks)
     out = {}
@@ -193,7 +218,8 @@ def lint(src="scan_bucket.hip", match="bscan3_kernel", extra=()):
             continue
         out[name] = {"resources": res.get(name, {}), "violations": inflight_violations(lines),
                      "scalar_loads": sum(1 for s in lines if s.startswith("s_load_dword")),
-                     "writelanes": sum(1 for s in lines if s.startswith("v_writelane"))}
+                     "writelanes": sum(1 for s in lines if s.startswith("v_writelane")),
+                     "hot_loop_spills": spills_in_hot_loops(lines)}
     return out
 
 
@@ -206,10 +232,10 @@ def main():
     rep = lint(args.src, args.match, tuple(args.extra))
     rc = 0
     for name, r in rep.items():
-        print(name, r["resources"], f"scalar loads {r['scalar_loads']}, v_writelane {r['writelanes']}, violations {len(r['violations'])}")
+        print(name, r["resources"], f"scalar loads {r['scalar_loads']}, v_writelane {r['writelanes']} ({len(r['hot_loop_spills'])} in hot loops), violations {len(r['violations'])}")
         for ins, regs in r["violations"][:20]:
             print("   ", ins, "<- in flight:", regs)
-        rc |= bool(r["violations"])
+        rc |= bool(r["violations"]) or any(x.startswith("v_writelane") for x in r["hot_loop_spills"])
     if not rep:
         print("no kernel matches", args.match)
         rc = 1

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--tag", default="")
     ap.add_argument("--metric", default="", choices=["", "l2", "cosine"], help="override the workload's metric (sift1m with cosine = the same buckets and candidates through the cosine bodies)")
     ap.add_argument("--l2-form", default="exact", choices=["exact", "folded"], help="folded: the opt-in 2-op L2 block (NLSH_METRIC_L2_EPS_FOLDED)")
+    ap.add_argument("--stress", type=int, default=0, help="repeat the scan N more times and count results that differ from the first one in any bit (the tiled schedule's results do not depend on timing: any difference is a race)")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--zeros", action="store_true", help="zero the grouped corpus and the queries after the index and the keys exist: same tasks and instruction stream, operands that toggle nothing (DVFS probe; pair with -DNLSH_ABLATE=5, ties change the selection)")
     ap.add_argument("--order", default="", choices=["", "pairs", "work", "density"], help="experiment: schedule order of the buckets recomputed on the host from THIS batch's keys (pairs: by (query, probe) pairs hitting the bucket; work: pairs x rows; density: full 16-query groups first, then by pairs), in place of the static size order")
@@ -106,6 +107,12 @@ def main():
         rec["pairs_share_by_group_size"] = {"16": float(((m - rem) * size).sum()) / tot, **{f"<={n}": float((rem * size)[(rem > 0) & (rem <= n)].sum()) / tot for n in (4, 8, 12, 15)}}
         segs = (size + 255) // 256
         rec["tasks_by_group_size"] = {"16": int(((m // 16) * segs).sum()), **{f"<={n}": int(segs[(rem > 0) & (rem <= n)].sum()) for n in (4, 8, 12, 15)}}
+    if args.stress:
+        bad = 0
+        for i in range(args.stress):
+            o = ix.scan_tensors(qg, keys, nkeys, k=10, check=False)
+            bad += int(not (torch.equal(o[0], dist) and torch.equal(o[1], idx) and torch.equal(o[2], nc)))
+        rec["stress_runs"], rec["stress_mismatches"] = args.stress, bad
     if not args.no_check:
         ref = Indexer(hashing, cg, dist_fn, compat=compat, algo="query")
         d0, i0, n0, _ = ref.scan_tensors(qg, keys, nkeys, k=10)
