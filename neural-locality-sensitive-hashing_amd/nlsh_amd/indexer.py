@@ -24,6 +24,26 @@ from .hashings import host_key_set, keys_to_sets
 HASH_BATCH = 4096  # nlsh/indexer.py:40 default batch_size
 
 
+def _load_fastlists():
+    """csrc/fastlists.c (built by the Makefile next to the HIP library): the result lists in one tight C loop.  Host-side and
+    optional -- `ndarray.tolist()` builds the identical lists -- unlike the HIP library, which has no substitute."""
+    import glob
+    import importlib.util
+    import os
+    for path in glob.glob(os.path.join(os.path.dirname(_capi.LIB_PATH), "_nlsh_fastlists*.so")):
+        spec = importlib.util.spec_from_file_location("_nlsh_fastlists", path)
+        try:
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            return mod.rows_to_lists
+        except ImportError:
+            continue
+    return None
+
+
+_rows_to_lists = _load_fastlists()
+
+
 def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
@@ -489,7 +509,10 @@ class Indexer:
             gc.collect(0)
         gc.disable()        # 10^4 fresh lists would trigger a dozen collections over the whole heap: a third of the conversion
         try:
-            out = idx_h.tolist(), nc_h.tolist()
+            if _rows_to_lists is not None and idx_h.dtype == np.int32 and idx_h.ndim == 2 and idx_h.flags.c_contiguous:
+                out = _rows_to_lists(idx_h, idx_h.shape[0], idx_h.shape[1]), nc_h.tolist()
+            else:
+                out = idx_h.tolist(), nc_h.tolist()
             if promote:
                 gc.freeze()
                 gc.unfreeze()

@@ -263,3 +263,21 @@ def test_deferred_result_release_is_opt_in_and_drops_the_older_result_under_the_
         assert rb() is None
     finally:
         Indexer.defer_result_release = False
+
+
+def test_fastlists_builds_the_same_lists_as_ndarray_tolist():
+    """csrc/fastlists.c: the host-side list builder of `Indexer._plain_lists` is `ndarray.tolist()` element for element (types too),
+    refuses a short buffer, and is what the facade uses when it is built."""
+    import numpy as np
+    from nlsh_amd import indexer
+    assert indexer._rows_to_lists is not None, "csrc/fastlists.c was not built (make -C csrc)"
+    rng = np.random.default_rng(5)
+    for shape in ((0, 10), (1, 1), (257, 10), (1000, 64)):
+        a = rng.integers(-1, 2 ** 31 - 1, size=shape).astype(np.int32)
+        got = indexer._rows_to_lists(a, shape[0], shape[1])
+        assert got == a.tolist() and all(type(v) is int for row in got for v in row)
+    with pytest.raises(ValueError):
+        indexer._rows_to_lists(np.zeros((4, 4), np.int32), 5, 4)
+    idx, nc = np.arange(5120, dtype=np.int32).reshape(512, 10), np.full((512,), 12, dtype=np.int32)
+    lists, counts = indexer.Indexer._plain_lists(idx, nc)
+    assert lists == idx.tolist() and counts == nc.tolist()
