@@ -227,13 +227,15 @@ class Indexer:
         return self._e_sb
 
     def choose_algo(self, Q, P):
-        """Bucket-major pays when a corpus row is a candidate of several queries of the batch
-        (expected (query, probe) pairs per row ~ Q * P * E[bucket size of a row] / N) AND the buckets are
-        big enough to fill its row tiles; otherwise (balanced hashes with small buckets, e.g. the GloVe
-        24-bit run: 104k buckets, size-biased mean 82 rows) the query-major stream keeps the call: r01 measured
-        0.21 ms against 0.41 / 0.52 ms; with r02's hand-scheduled k-blocks (L2 and cosine) the tiled schedule has caught up
-        there (scan 0.199 vs 0.215 ms, sequential step 0.290 vs 0.312 ms at 10^4 queries; within 2 % at 5,000 and fewer;
-        equal through the batch pipeline), which is not enough to move a threshold on."""
+        """Bucket-major pays when a corpus row is a candidate of several queries of the batch: expected (query, probe) pairs per row
+        `reuse` ~ Q * P * E[bucket size of a row] / N.  The LDS-tiled schedule fetches a row once per 16 queries and needs no
+        cross-lane reduction; it takes the call from reuse >= 6 on, provided the buckets fill at least one 64-row tile on average
+        (size-biased mean >= 64 rows).  Measured boundaries (r03, profiles/r03_bench_glove*.json): the GloVe-1.2M-shaped run --
+        104 k buckets, size-biased mean 82 rows, reuse 6.9 -- scans in 0.217 ms tiled against 0.234 ms query-major (sequential step
+        0.247 vs 0.268 ms; r02: 0.199 vs 0.215), so it sits on the tiled side; r01's kernels had it the other way round (0.41 vs
+        0.21 ms), which is where the old `e_sb >= 256 and reuse >= 8` rule came from.  Below that, big buckets with moderate sharing
+        go to the wave-level bucket-major schedule, everything else (balanced hashes with tiny buckets, small batches) to the
+        query-major stream.  The rule is deterministic in whole-corpus statistics, so every shard count picks the same arithmetic."""
         if self.algo is not None:
             return {"query": _capi.SCAN_QUERY_MAJOR, "bucket": _capi.SCAN_BUCKET_MAJOR, "tiled": _capi.SCAN_BUCKET_TILED}[self.algo]
         if self.schedule_stats is not None:
@@ -242,7 +244,7 @@ class Indexer:
             e_sb = self._size_biased_bucket()
             n = max(float(self.bucket_sizes.sum()), 1.0)
         reuse = Q * P * e_sb / n
-        if e_sb >= 256 and reuse >= 8.0:
+        if e_sb >= 64 and reuse >= 6.0:
             return _capi.SCAN_BUCKET_TILED
         if e_sb >= 128 and reuse >= 3.0:
             return _capi.SCAN_BUCKET_MAJOR

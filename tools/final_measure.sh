@@ -9,7 +9,7 @@ python -m pytest tests -m gpu -q -x 2>&1 | tail -2 > $O/tests.txt
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --data clusters --no-cpu-baseline > $O/bench_clusters.json 2>/dev/null
 python bench.py --workload glove --no-cpu-baseline --pipeline on > $O/bench_glove.json 2>/dev/null
-python bench.py --workload glove --no-cpu-baseline --pipeline on --algo tiled > $O/bench_glove_tiled.json 2>/dev/null
+python bench.py --workload glove --no-cpu-baseline --pipeline on --algo query > $O/bench_glove_query_major.json 2>/dev/null
 for w in 1 2 4 8; do python tools/shard_step_profile.py --world $w --rank 0 --steps 50; done 2>/dev/null > $O/shard_step_profile.jsonl
 if [ -f $R/neural-locality-sensitive-hashing_amd/lib/libnlsh_hip_trace.so ]; then
   NLSH_HIP_LIB=$R/neural-locality-sensitive-hashing_amd/lib/libnlsh_hip_trace.so python tools/scan_clock.py > $O/scan_clock.txt 2>/dev/null || true
@@ -18,6 +18,7 @@ cd /tmp && export TMPDIR=/tmp
 # per-kernel statistics of the bench command (one row range per query() call: every scan launch has the full-batch grid)
 rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --no-cpu-baseline --query-chunks 1 > $O/bench_under_rocprof.json 2> /tmp/kt.err
 cp $(find /tmp/kt -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
+python3 $R/tools/kernel_trace_regions.py /tmp/kt > $O/kernel_trace_regions.txt
 # counters of the same command (their own pass: no tracing domains beside --pmc)
 rm -rf /tmp/pm && rocprofv3 --pmc FETCH_SIZE SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/pm -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 --query-chunks 1 > /tmp/pm.out 2> /tmp/pm.err
 python3 $R/tools/pmc_summary.py /tmp/pm > $O/pmc.json
