@@ -310,6 +310,7 @@ class ShardedIndexer:
             _, idx, nc = gather_and_merge(keys64, ncand, k, self.group)
         Q = idx.shape[0]
         lo, hi = shard_range(Q, rank, world) if own_slice else (0, Q)
+        local._release_held()      # the device (and the collective) are busy: free what an earlier call left with us (opt-in, Indexer.defer_result_release)
         idx_h, nc_h = idx[lo:hi].cpu().numpy(), nc[lo:hi].cpu().numpy()
         results, counts = local._plain_lists(idx_h, nc_h)                        # short lists are replaced below
         # queries with fewer than k candidates (rare)
@@ -326,4 +327,4 @@ class ShardedIndexer:
         elif short.size:
             for j in short.tolist():
                 results[j] = [int(v) for v in idx_h[j] if v >= 0]
-        return results, counts
+        return local._keep((results, counts))
