@@ -311,19 +311,43 @@ __global__ __launch_bounds__(256) void bscan_kernel(BArgs a, int plan_blocks) {
             if (bad) a.status[1] = 2;
         }
     }
+    // A bucket's descriptors are written by its own thread (writing a block's tasks with all its threads, one task per thread and
+    // round, measured 15.6 us against 9.5 us on the SIFT1M-shaped batch) -- unless it has more than HEAVY of them: a 180 k-row
+    // bucket probed by thousands of queries (Deep100M-shaped: 707 segments x hundreds of query groups) is 10^5 descriptors, and one
+    // thread writing them made this kernel 1.0 ms of a 37-ms step (r03).  Heavy buckets are queued in LDS and written by the whole block.
+    constexpr int HEAVY = 256, HEAVY_SLOTS = 256;
+    __shared__ int heavy_n;
+    __shared__ int heavy_b[HEAVY_SLOTS][6];   // po, to, ng, nt, m, bucket (row0 and size are re-read)
+    if (threadIdx.x == 0) heavy_n = 0;
     __syncthreads();
     if (i < a.nb && !bad) {
         const int po = base_m + ex_m, to = base_t + ex_t;
         a.pairoff[b] = po;
         a.taskoff[b] = to;
-        const int row0 = a.offsets[b];
-        for (int t = 0; t < nt; ++t) {   // (writing a block's tasks with all its threads, one task per thread and round, measured 15.6 us against 9.5 us)
+        if (nt > HEAVY) {
+            const int slot = atomicAdd(&heavy_n, 1);   // <= 256 threads, so a slot always exists
+            heavy_b[slot][0] = po; heavy_b[slot][1] = to; heavy_b[slot][2] = ng; heavy_b[slot][3] = nt; heavy_b[slot][4] = m; heavy_b[slot][5] = b;
+        } else {
+            const int row0 = a.offsets[b];
+            for (int t = 0; t < nt; ++t) {
+                const long long tt = (long long)to + t;
+                if (tt >= a.max_tasks) break;
+                // segment-major: the query groups of one row segment get consecutive task ids, so they run
+                // at about the same time (and, with the chunked XCD map of bscan3, on one XCD's L2)
+                const int si = t / ng, gi = t - si * ng;
+                a.task[tt] = make_int4(po + gi * a.QB, min(a.QB, m - gi * a.QB), row0 + si * a.seg, min(a.seg, s - si * a.seg));
+            }
+        }
+    }
+    __syncthreads();
+    for (int h = 0; h < heavy_n; ++h) {
+        const int po = heavy_b[h][0], to = heavy_b[h][1], hng = heavy_b[h][2], hnt = heavy_b[h][3], hm = heavy_b[h][4], hb = heavy_b[h][5];
+        const int row0 = a.offsets[hb], hs = a.offsets[hb + 1] - row0;
+        for (int t = threadIdx.x; t < hnt; t += 256) {
             const long long tt = (long long)to + t;
             if (tt >= a.max_tasks) break;
-            // segment-major: the query groups of one row segment get consecutive task ids, so they run
-            // at about the same time (and, with the chunked XCD map of bscan3, on one XCD's L2)
-            const int si = t / ng, gi = t - si * ng;
-            a.task[tt] = make_int4(po + gi * a.QB, min(a.QB, m - gi * a.QB), row0 + si * a.seg, min(a.seg, s - si * a.seg));
+            const int si = t / hng, gi = t - si * hng;
+            a.task[tt] = make_int4(po + gi * a.QB, min(a.QB, hm - gi * a.QB), row0 + si * a.seg, min(a.seg, hs - si * a.seg));
         }
     }
 }

@@ -136,6 +136,9 @@ __device__ __forceinline__ uint64_t select_k_smallest(const uint64_t (&key)[NK],
         // invariants: #{hi <= b} >= k (b = max: all n > k keys) and #{hi < a} < k (a = min: none)
         bool split = false;
         if (n == k) { a = b; split = true; }   // all present keys are taken: the cut is the largest of them
+#if defined(NLSH_ABLATE) && NLSH_ABLATE == 11   // diagnostic timing build (WRONG results): no bisection at all -- what the search for the cut costs
+        a = b; split = true;
+#endif
         while (a < b) {
             const uint32_t mid = a + ((b - a) >> 1);
             int cnt = 0;
@@ -172,7 +175,11 @@ __device__ __forceinline__ uint64_t select_k_smallest(const uint64_t (&key)[NK],
         const bool sel = key[i] != KEY_NONE && (hi[i] < dk || (hi[i] == dk && lo[i] <= idk));
         const unsigned long long m = __ballot(sel);
         const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+#if defined(NLSH_ABLATE) && NLSH_ABLATE == 11
+        if (sel && pos < k) {
+#else
         if (sel && (!CLAMP || pos < k)) {
+#endif
             if (AGENT) __hip_atomic_store(reinterpret_cast<unsigned long long *>(out) + pos, (unsigned long long)key[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else out[pos] = key[i];
         }
