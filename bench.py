@@ -244,12 +244,11 @@ def main():
 
     # ------------------------------------------------------------------ region A: the reference's protocol (headline)
     # `value`: every call returns ALL Q result lists to the calling rank, at every N (the reference's deliverable,
-    # nlsh/trainers/base.py:93-96).  The conversion runs with the facade's opt-in GC promotion ON (Indexer.promote_results,
-    # INTEGRATION.md); the same region with the facade's default (off) is reported beside it, and at N>1 the variant in which
-    # rank r only builds the lists of its Q/N slice of the batch (`own_slice_qps`).
-    def protocol_region(own, promote):
-        Indexer.promote_results = promote
-        Indexer.defer_result_release = promote    # the two opt-in host-side behaviours of query() go together
+    # nlsh/trainers/base.py:93-96), with the facade's opt-in `Indexer.defer_result_release` ON (the previous call's dead lists are
+    # freed under the next call's scan); the same region with the facade's defaults is reported beside it
+    # (`protocol_qps_default`), and at N>1 the variant in which rank r only builds the lists of its Q/N slice (`own_slice_qps`).
+    def protocol_region(own, defer):
+        Indexer.defer_result_release = defer
 
         def query_lists(i):
             if sharded is not None:   # same seed on every rank
@@ -268,16 +267,15 @@ def main():
             calls.append(time.perf_counter() - t1)
         fence()
         el = max_over_ranks(time.perf_counter() - t0)
-        Indexer.promote_results = False
         Indexer.defer_result_release = False
         return el, calls, held
 
-    elapsed, call_s, (ids_api, nc_api) = protocol_region(own=False, promote=True)
+    elapsed, call_s, (ids_api, nc_api) = protocol_region(own=False, defer=True)
     assert isinstance(ids_api, list) and len(ids_api) == Q and isinstance(nc_api, list)
-    elapsed_default_gc, _, _ = protocol_region(own=False, promote=False)
+    elapsed_default, _, _ = protocol_region(own=False, defer=False)
     elapsed_own = None
     if sharded is not None:
-        elapsed_own, _, (ids_own, _) = protocol_region(own=True, promote=True)
+        elapsed_own, _, (ids_own, _) = protocol_region(own=True, defer=True)
         q_lo, q_hi = shard_range(Q, rank, world)
         assert len(ids_own) == q_hi - q_lo
 
@@ -480,11 +478,10 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "recall_at_10": recall,
             "value_protocol": "Indexer.query(batch, k, hash_times) -> Python lists of ALL Q queries on the calling rank, K synchronous calls "
-                              "(nlsh/trainers/base.py:93-96); Indexer.promote_results=True and Indexer.defer_result_release=True (the two opt-in host-side "
-                              "behaviours of query(): GC promotion of the result lists, release of the previous call's lists under the next call's scan; "
-                              "INTEGRATION.md; protocol_qps_default_gc has both off)" + ("" if world == 1 else f"; sharded x{world}: every rank scans all queries over its shard, one "
+                              "(nlsh/trainers/base.py:93-96); Indexer.defer_result_release=True (opt-in: the previous call's dead lists are freed under the "
+                              "next call's scan; INTEGRATION.md; protocol_qps_default is the same region with the facade's defaults)" + ("" if world == 1 else f"; sharded x{world}: every rank scans all queries over its shard, one "
                                                     "all-gather + merge, every rank builds all Q lists"),
-            "protocol_qps_default_gc": Q * steps / elapsed_default_gc,
+            "protocol_qps_default": Q * steps / elapsed_default,
             "own_slice_qps": None if elapsed_own is None else Q * steps / elapsed_own,
             "protocol_median_qps": Q / float(np.median(call_s)),
             "protocol_call_ms": [round(1e3 * c, 3) for c in call_s],

@@ -276,6 +276,10 @@ def test_fastlists_builds_the_same_lists_as_ndarray_tolist():
         a = rng.integers(-1, 2 ** 31 - 1, size=shape).astype(np.int32)
         got = indexer._rows_to_lists(a, shape[0], shape[1])
         assert got == a.tolist() and all(type(v) is int for row in got for v in row)
+        assert all(type(row) is list for row in got)
+        # the inner lists (ints only: no cycle possible) are handed out untracked by the cyclic GC, the outer list is an ordinary one
+        import gc
+        assert gc.is_tracked(got) and not any(gc.is_tracked(row) for row in got)
     with pytest.raises(ValueError):
         indexer._rows_to_lists(np.zeros((4, 4), np.int32), 5, 4)
     idx, nc = np.arange(5120, dtype=np.int32).reshape(512, 10), np.full((512,), 12, dtype=np.int32)

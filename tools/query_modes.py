@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Same-box comparison of the host-side modes of `Indexer.query()` on the headline workload (ms per call over a loop that keeps
+only the latest result, like bench.py's protocol region): numpy `tolist()` vs csrc/fastlists.c (inner lists untracked by the GC),
+`promote_results` and `defer_result_release` on / off, 1 or 2 row ranges."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "neural-locality-sensitive-hashing_amd")):
+    sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from nlsh_amd import indexer as ixmod, io, synth  # noqa: E402
+from nlsh_amd.data import SIFT  # noqa: E402
+from nlsh_amd.indexer import Indexer  # noqa: E402
+
+N, d, Q = 1_000_000, 128, 10_000
+corpus_h, mean, std = synth.standardise(synth.sift_manifold(N, d, seed=synth.SEED_DATA))
+Ws, bs = io.load_hasher_weights(os.path.join(ROOT, "neural-locality-sensitive-hashing_amd", "checkpoints", "sift1m_manifold_h16.npz"))
+ix = Indexer(io.hashing_from_weights(Ws, bs, compat=True), torch.from_numpy(corpus_h).cuda(), SIFT.distance)
+qb = [torch.from_numpy(synth.standardise(synth.sift_manifold(Q, d, seed=synth.SEED_QUERY + 17 * i), mean, std)[0]).cuda() for i in range(4)]
+fast = ixmod._rows_to_lists
+
+
+def run(builder, promote, defer, chunks, n=60):
+    ixmod._rows_to_lists = builder
+    Indexer.promote_results, Indexer.defer_result_release, Indexer.query_chunks = promote, defer, chunks
+    keep = None
+    for i in range(8):
+        keep = ix.query(qb[i % 4], 10, 10)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        keep = ix.query(qb[i % 4], 10, 10)
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / n
+
+
+rows = []
+for rep in range(2):
+    for name, builder, promote, defer, chunks in (
+            ("tolist, defaults (2 ranges)", None, False, False, None),
+            ("tolist + promote + defer", None, True, True, None),
+            ("fastlists, defaults (2 ranges)", fast, False, False, None),
+            ("fastlists, defaults, 1 range", fast, False, False, 1),
+            ("fastlists + defer", fast, False, True, None),
+            ("fastlists + promote + defer", fast, True, True, None)):
+        if builder is None or fast is not None:
+            rows.append((name, round(run(builder, promote, defer, chunks), 4)))
+Indexer.promote_results, Indexer.defer_result_release, Indexer.query_chunks = False, False, None
+ixmod._rows_to_lists = fast
+print(json.dumps(rows))
