@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NLSH_ABI_VERSION 1
+#define NLSH_ABI_VERSION 2   /* 2 (r04): cells (nlsh_build_cells, nlsh_scan_topk_cells_phase); nlsh_scan_workspace_layout reports the row ranges */
 
 typedef void *nlsh_stream_t; /* hipStream_t */
 
@@ -123,6 +123,25 @@ size_t nlsh_bucket_order_workspace(int64_t n_buckets);
 int nlsh_bucket_order(const int32_t *offsets, int64_t n_buckets, int32_t *order_out, void *workspace,
                       size_t workspace_bytes, nlsh_stream_t stream);
 
+/* Cells: small-bucket packing for the LDS-tiled scan (NLSH_SCAN_BUCKET_TILED).  A task of that schedule is one workgroup on
+ * (<= 256 consecutive rows of corpus_sorted) x (<= 16 queries) and costs ~9 us before its first distance; with one task per
+ * (bucket, query group) a balanced hash with tiny buckets (GloVe-1.2M-shaped: 104 k buckets, ~1 probing query per touched bucket and
+ * batch) pays that latency once per (query, bucket) pair.  The sorted corpus is bucket-contiguous, so consecutive small buckets are
+ * consecutive rows: a CELL is either one bucket of more than window_rows rows, or a greedy run (CSR order, restarted every 1024
+ * buckets so that the packing is a pure function of (offsets, window_rows)) of consecutive buckets of <= window_rows rows whose rows
+ * total <= window_rows.  The scan then counts (query, probe) pairs and lays out tasks per CELL: the queries probing any bucket of a
+ * window share its tasks, and each (task, query) carries the row range of ITS bucket inside the window, applied when the top-k is
+ * selected -- every distance is still the same k-ascending fmaf chain over the same row, so results are bit-identical with and without
+ * cells, for every window_rows.  What changes is the number of tasks (fewer, fuller) against rows scored for queries that do not own
+ * them (window_rows 64 adds none: a lone tiny bucket already costs a 64-row tile).
+ * Outputs [dev]: cell_of [n_buckets] bucket -> cell; cell_offsets [n_buckets + 1] first sorted row of each cell (entries from
+ * *n_cells on hold N); cell_order [n_buckets] cells by descending rows (first *n_cells entries valid) = the bucket_order argument
+ * of the scan when cells are passed; n_cells [1].  window_rows in [1, 256].  No reference counterpart (the reference walks
+ * `for key in index_keys`, nlsh/indexer.py:66, one gather per key); changes speed, never results. */
+size_t nlsh_build_cells_workspace(int64_t n_buckets);
+int nlsh_build_cells(const int32_t *offsets, int64_t n_buckets, int window_rows, int32_t *cell_of, int32_t *cell_offsets,
+                     int32_t *cell_order, int32_t *n_cells, void *workspace, size_t workspace_bytes, nlsh_stream_t stream);
+
 /* Re-order the corpus bucket-contiguously: sorted[i, :] = corpus[perm[i], :], zero padded to
  * dst_stride floats (dst_stride % 4 == 0, >= d).  Replaces the per-(query,key) index_select
  * gather of nlsh/indexer.py:77-82 by a one-time permutation.  inv_norm (nullable) [n] receives
@@ -174,10 +193,12 @@ int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, int d, const 
 
 /* Diagnostic, for tests of the bucket-major schedules (algo 1, 2): byte offsets, inside a workspace of this shape, of the
  * task table the PLAN phase leaves there -- int32 [status[0]][4] = {first pair of the query group, queries in the group,
- * first corpus row of the segment, rows in the segment} -- and (algo 2 only) of the tasks' query ids, int32 [max_tasks][16].
+ * first corpus row of the segment, rows in the segment} -- and (algo 2 only) of the tasks' query ids, int32 [max_tasks][16], and
+ * of each (task, query)'s row range inside the task's rows, int32 [max_tasks][16] = lo | hi << 16 (the rows of the query's own
+ * bucket: the whole segment without cells, the bucket's slice of a shared window with them).  Any out pointer may be NULL.
  * No reference counterpart: the reference has no schedule (it walks `for key in index_keys`, nlsh/indexer.py:66). */
 int nlsh_scan_workspace_layout(int64_t Q, int P, int k, int64_t max_tasks, int64_t n_buckets, int d, int algo,
-                               size_t *task_table_offset, size_t *task_queries_offset);
+                               size_t *task_table_offset, size_t *task_queries_offset, size_t *task_ranges_offset);
 
 /* The same call cut in three, for callers that pipeline batches over streams: NLSH_PHASE_PLAN runs everything up
  * to the scan kernel (bucket lookup, task table; touches status and the workspace, the query-major schedule also out_ncand),
@@ -197,6 +218,18 @@ int nlsh_scan_topk_phase(const float *corpus_sorted, int64_t row_stride, int d, 
                          float *out_dist, int32_t *out_idx, uint64_t *out_keys, int32_t *out_ncand,
                          int32_t *status, void *workspace, size_t workspace_bytes, int64_t max_tasks,
                          void *ev_scan_begin, void *ev_scan_end, nlsh_stream_t stream, int phases);
+
+/* nlsh_scan_topk_phase on an index with cells (nlsh_build_cells): cell_of [dev] [n_buckets], cell_offsets [dev] [n_cells + 1],
+ * and `bucket_order` = the cell order [n_cells] (or NULL).  n_cells = 0 (pointers NULL) is nlsh_scan_topk_phase.  Cells only
+ * change the task layout of algo NLSH_SCAN_BUCKET_TILED; the other schedules ignore them.  Same outputs, bit for bit. */
+int nlsh_scan_topk_cells_phase(const float *corpus_sorted, int64_t row_stride, int d, const int32_t *gid,
+                               const int32_t *uniq_keys, const int32_t *offsets, const int32_t *bucket_order, int32_t n_buckets,
+                               const int32_t *cell_of, const int32_t *cell_offsets, int32_t n_cells,
+                               const float *inv_norm, const float *queries, int64_t q_stride, int64_t Q,
+                               const int32_t *qkeys, const int32_t *nkeys, int P, int k, int metric, int algo, int seg_rows,
+                               float *out_dist, int32_t *out_idx, uint64_t *out_keys, int32_t *out_ncand,
+                               int32_t *status, void *workspace, size_t workspace_bytes, int64_t max_tasks,
+                               void *ev_scan_begin, void *ev_scan_end, nlsh_stream_t stream, int phases);
 
 /* Merge G per-shard top-k lists per query (keys_in [dev] [G, Q, row_stride] u64, the first k of each
  * row as all-gathered from nlsh_scan_topk's out_keys) into the global top-k; same comparator, so the

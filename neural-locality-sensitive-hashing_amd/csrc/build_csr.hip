@@ -88,6 +88,64 @@ __global__ void bucket_sizes_kernel(const int32_t *offsets, long long nb, uint32
     }
 }
 
+
+// ---- cells: runs of consecutive small buckets that share one row window of the tiled scan ------------------------------------
+// Greedy packing in CSR order: a bucket of more than `W` rows is a cell of its own; consecutive buckets of <= W rows are packed
+// into one cell while the cell's rows stay <= W.  One WAVEFRONT packs CELL_SPAN consecutive buckets (the packing restarts at every
+// span boundary, so the result is a pure function of (offsets, W) and the spans are independent): it holds 64 buckets at a time,
+// one per lane, and takes one ballot per CELL, not per bucket -- the lanes past the open cell's last fitting bucket vote, the
+// first of them starts the next cell.
+constexpr int CELL_SPAN = 1024;
+
+__global__ __launch_bounds__(256) void cell_flags_kernel(const int32_t *offsets, long long nb, int W, int32_t *flags) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long b0 = wave * CELL_SPAN;
+    if (b0 >= nb) return;
+    int cur = -1;   // first row of the open cell; -1: none (span start, or the previous bucket was a big one)
+    for (int ch = 0; ch < CELL_SPAN / 64; ++ch) {
+        const long long cb = b0 + (long long)ch * 64;
+        if (cb >= nb) break;
+        const long long b = cb + lane;
+        const int nvalid = (int)min((long long)64, nb - cb);
+        const int s = b < nb ? offsets[b] : 0, e = b < nb ? offsets[b + 1] : 0;
+        const bool small = (e - s) <= W;
+        unsigned long long starts = 0;
+        int pos = 0;
+        while (pos < nvalid) {
+            const int s_p = __builtin_amdgcn_readlane(s, pos), e_p = __builtin_amdgcn_readlane(e, pos);
+            if (e_p - s_p > W) {          // big bucket: a cell of its own, and nothing is open behind it
+                starts |= 1ull << pos;
+                cur = -1;
+                ++pos;
+                continue;
+            }
+            if (cur < 0 || e_p - cur > W) {   // does not fit the open cell: it opens the next one
+                starts |= 1ull << pos;
+                cur = s_p;
+            }
+            const unsigned long long stop = __ballot(lane > pos && lane < nvalid && (!small || e - cur > W));
+            pos = stop ? __ffsll((long long)stop) - 1 : nvalid;
+        }
+        if (b < nb) flags[b] = (int32_t)((starts >> lane) & 1ull);
+    }
+}
+
+// rank = inclusive prefix sum of the flags: cell of bucket b = rank[b] - 1.  cell_offsets is written for ALL nb + 1 slots (slots past
+// the last cell hold N: zero-row cells), so the size sort below can run on nb entries without the host knowing the cell count.
+__global__ void emit_cells_kernel(const int32_t *offsets, const int32_t *flags, const int32_t *rank, long long nb, int32_t *cell_of,
+                                  int32_t *cell_offsets, int32_t *n_cells) {
+    const int32_t nc = rank[nb - 1], n_rows = offsets[nb];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i <= nb; i += (long long)gridDim.x * blockDim.x) {
+        if (i < nb) {
+            cell_of[i] = rank[i] - 1;
+            if (flags[i]) cell_offsets[rank[i] - 1] = offsets[i];
+        }
+        if (i >= nc) cell_offsets[i] = n_rows;
+        if (i == 0) *n_cells = nc;
+    }
+}
+
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct OrderWs {
@@ -204,6 +262,64 @@ extern "C" int nlsh_bucket_order(const int32_t *offsets, int64_t n_buckets, int3
     NLSH_CHECK_HIP(rocprim::radix_sort_pairs_desc(base + w.tmp, tb, sizes, sorted_sizes, idx, order_out, (size_t)n_buckets, 0, 32, s));
     NLSH_CHECK_HIP(hipGetLastError());
     return NLSH_OK;
+}
+
+struct CellWs {
+    size_t flags, rank, tmp, tmp_bytes, order, total;
+};
+static int cell_layout(long long nb, CellWs *w, hipStream_t s) {
+    const size_t n4 = align_up((size_t)(nb > 0 ? nb : 1) * 4);
+    size_t t_scan = 0;
+    int32_t *nul = nullptr;
+    hipError_t e = rocprim::inclusive_scan(nullptr, t_scan, nul, nul, (size_t)nb, rocprim::plus<int32_t>(), s);
+    if (e != hipSuccess) { set_error("rocprim::inclusive_scan size query: %s", hipGetErrorString(e)); return NLSH_E_HIP; }
+    OrderWs ow;
+    int rc = order_layout(nb, &ow, s);
+    if (rc != NLSH_OK) return rc;
+    w->flags = 0;
+    w->rank = n4;
+    w->tmp = 2 * n4;
+    w->tmp_bytes = align_up(t_scan);
+    w->order = w->tmp + w->tmp_bytes;
+    w->total = w->order + ow.total;
+    return NLSH_OK;
+}
+
+extern "C" size_t nlsh_build_cells_workspace(int64_t n_buckets) {
+    if (n_buckets < 0) { set_error("build_cells_workspace: n_buckets=%lld", (long long)n_buckets); return 0; }
+    CellWs w;
+    if (cell_layout(n_buckets, &w, nullptr) != NLSH_OK) return 0;
+    return w.total;
+}
+
+extern "C" int nlsh_build_cells(const int32_t *offsets, int64_t n_buckets, int window_rows, int32_t *cell_of, int32_t *cell_offsets,
+                                int32_t *cell_order, int32_t *n_cells, void *workspace, size_t workspace_bytes, nlsh_stream_t stream) {
+    NLSH_REQUIRE(n_buckets >= 0 && n_buckets < (1ll << 31), NLSH_E_INVALID, "build_cells: n_buckets=%lld", (long long)n_buckets);
+    NLSH_REQUIRE(window_rows >= 1 && window_rows <= 256, NLSH_E_UNSUPPORTED, "build_cells: window_rows=%d not in [1,256] (one segment of the tiled scan)", window_rows);
+    NLSH_REQUIRE(n_cells, NLSH_E_INVALID, "build_cells: null output");
+    hipStream_t s = (hipStream_t)stream;
+    if (n_buckets == 0) {
+        NLSH_CHECK_HIP(hipMemsetAsync(n_cells, 0, sizeof(int32_t), s));
+        return NLSH_OK;
+    }
+    NLSH_REQUIRE(offsets && cell_of && cell_offsets && cell_order && workspace, NLSH_E_INVALID, "build_cells: null pointer");
+    CellWs w;
+    int rc = cell_layout(n_buckets, &w, s);
+    if (rc != NLSH_OK) return rc;
+    NLSH_REQUIRE(workspace_bytes >= w.total, NLSH_E_WORKSPACE, "build_cells: workspace %zu < %zu", workspace_bytes, w.total);
+    char *base = (char *)workspace;
+    int32_t *flags = (int32_t *)(base + w.flags), *rank = (int32_t *)(base + w.rank);
+    const long long spans = (n_buckets + CELL_SPAN - 1) / CELL_SPAN;
+    hipLaunchKernelGGL(cell_flags_kernel, dim3((unsigned)((spans + 3) / 4)), dim3(256), 0, s, offsets, (long long)n_buckets, window_rows, flags);
+    size_t tb = w.tmp_bytes;
+    NLSH_CHECK_HIP(rocprim::inclusive_scan(base + w.tmp, tb, flags, rank, (size_t)n_buckets, rocprim::plus<int32_t>(), s));
+    int grid = (int)((n_buckets + 256) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(emit_cells_kernel, dim3(grid), dim3(256), 0, s, offsets, flags, rank, (long long)n_buckets, cell_of, cell_offsets, n_cells);
+    NLSH_CHECK_HIP(hipGetLastError());
+    // schedule order of the cells: by descending rows over all n_buckets slots (the zero-row slots past the last cell sort behind
+    // every real cell, so the first *n_cells entries are the order of the cells)
+    return nlsh_bucket_order(cell_offsets, n_buckets, cell_order, base + w.order, workspace_bytes - w.order, stream);
 }
 
 extern "C" int nlsh_gather_rows(const float *corpus, int64_t src_stride, int d, const int32_t *perm, int64_t n,

@@ -64,26 +64,7 @@ extern "C" int nlsh_debug_scan_trace(float *host, int n_floats) {
 #ifndef NLSH_FAT_STAGES
 #define NLSH_FAT_STAGES 1
 #endif
-// 1: the tiled schedule stages its k-blocks by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write) into a
-// DOUBLE-buffered, XOR-swizzled tile, one barrier per k-block (l2_task_glds); 0: register staging into one padded tile, two
-// barriers per k-block (l2_task).  Same arithmetic in the same order: bit-identical results.
-#ifndef NLSH_TILED_GLDS
-#define NLSH_TILED_GLDS 0
-#endif
-// Diagnostic timing builds only (WRONG results: the waves of a workgroup race on the tile): 1 = the stage barriers of the register-
-// staging task body are removed, which decouples the four waves of a workgroup -- what the barriers' straggler coupling costs.
-// 1 (experiment, r03; OFF): in the tiled schedule the LAST partial list of a query to be written merges all of the query's lists right
-// there, inside the scan launch (a per-query countdown set up by the PLAN phase; lists travel through agent-scope stores and loads,
-// no fence), and the MERGE phase has nothing left to launch.  Correct -- the GPU suite and 600 repeated full-size scans without one
-// differing bit -- but it removes a 16-us kernel and makes the scan 36 us longer (0.269 -> 0.305 ms, profiles/r03_merge_in_scan_ab.txt):
-// every wave ends its task behind an `s_waitcnt vmcnt(0)` on write-through stores and a returning atomic, ~4 us of a 30-50 us task
-// during which its slot holds no work.  0 (shipped): bmerge_kernel.
-#ifndef NLSH_MERGE_IN_SCAN
-#define NLSH_MERGE_IN_SCAN 0
-#endif
-#ifndef NLSH_NO_STAGE_BARRIER
-#define NLSH_NO_STAGE_BARRIER 0
-#endif
+// (NLSH_ABLATE / NLSH_NO_STAGE_BARRIER: diagnostic switches, defined in scan_common.h, live only under -DNLSH_DIAG)
 #define NLSH_STAGE_SYNC() do { if (!NLSH_NO_STAGE_BARRIER) __syncthreads(); } while (0)
 
 #ifndef NLSH_TILED_MIN_WAVES
@@ -103,9 +84,6 @@ extern "C" int nlsh_debug_scan_trace(float *host, int n_floats) {
 #define NLSH_FAST_KBLOCK 1  // hand-scheduled k-blocks for full L2 tasks (0: compiler-scheduled loop everywhere, for A/B)
 #endif
 
-#ifndef NLSH_ABLATE
-#define NLSH_ABLATE 0  // diagnostic timing builds only: 1 no distance math, 2 no global loads, 3 no top-k selection, 4 no scalar loads (generic loop), 5 no epilogue, 6 neither math nor epilogue (staging skeleton)
-#endif
 
 namespace nlsh {
 
@@ -117,6 +95,12 @@ struct BArgs {
     const int32_t *uniq;
     const int32_t *offsets;
     int nb;
+    // Cells (nlsh_build_cells; tiled schedule): the unit the PLAN phase counts pairs and lays out tasks by.  A cell is a big bucket on
+    // its own, or a run of consecutive small buckets of at most `window_rows` (<= 256) rows that share one row window -- the
+    // queries probing ANY of them share the window's tasks, each with its own row range.  Without cells: cell == bucket.
+    const int32_t *cell_of;    // [nb] bucket -> cell, or nullptr
+    const int32_t *coffsets;   // [nc + 1] first sorted row of every cell (== offsets without cells)
+    int nc;                    // cells (== nb without cells)
     const float *inv_norm;
     const float *queries;
     long long q_stride;
@@ -129,18 +113,17 @@ struct BArgs {
     uint64_t *out_keys;
     int32_t *out_ncand;
     int32_t *status;
-    int32_t *pbkt, *inv_q, *bcount, *pairoff, *taskoff, *bgroups, *counters;
+    int32_t *pbkt, *inv_q, *bcount, *pairoff, *taskoff, *bgroups, *counters;   // bcount / pairoff / taskoff / bgroups are per CELL
     int4 *prec;  // [Q*P] per (query, probe): {first task of its query group, slot in the group, bucket rows, query groups}; .z = 0: no bucket
     int4 *task;
     int32_t *task_q;   // tiled schedule: [max_tasks][16] query ids of every task (its group's slice of inv_q, repeated per row segment)
+    int32_t *task_r;   // tiled schedule: [max_tasks][16] row range of every (task, query) inside the task's rows, lo | hi << 16: the rows of the
+                       // query's bucket (a whole segment of a big bucket; the bucket's slice of a shared window)
     uint64_t *partial;
     long long max_tasks;
-    const int32_t *border;     // [nb] schedule order of the buckets (largest first) or nullptr = CSR order
+    const int32_t *border;     // [nc] schedule order of the cells (largest first) or nullptr = CSR order
     int32_t *btot;             // [3 * blocks of bscan] per-block (pairs, tasks, negative counters) totals
     int32_t *hits;             // [blocks of bplan] (query, probe) pairs each bplan block found a bucket for
-    int merge_in_scan;         // 1: tiled schedule with NLSH_MERGE_IN_SCAN (PLAN prefills the outputs and the countdowns, the scan merges)
-    int32_t *remaining;        // [Q] tiled schedule, NLSH_MERGE_IN_SCAN: partial lists of the query not yet written (bscatter adds a probe's
-                               // row segments, every finished list takes one off; whoever takes the last one merges the query)
     unsigned long long *tauq;  // [Q] running upper bound of each query's k-th best key (atomicMin), KEY_NONE-initialised
     const float *qpad;  // tiled variant: queries padded to d4p*4 floats (L2: pad = -eps; cosine: pre-normalised, pad = 0)
     float *qpad_w;      // same buffer, writable (bprep); qpad aliases `queries` when no padding/normalisation is needed
@@ -163,18 +146,7 @@ __global__ __launch_bounds__(256) void bplan_kernel(BArgs a, int stride) {
     if (idx < a.Q * a.P) {
         const long long q = idx / a.P;
         const int p = (int)(idx - q * a.P);
-        if (p == 0) {
-            a.tauq[q] = KEY_NONE;        // running bound of the query
-            if (a.merge_in_scan) {        // the scan merges a query when its last list lands; a query without lists keeps this empty result
-                a.remaining[q] = 0;
-                a.out_ncand[q] = 0;
-                for (int e = 0; e < a.k; ++e) {
-                    a.out_dist[q * a.k + e] = __builtin_inff();
-                    a.out_idx[q * a.k + e] = -1;
-                    if (a.out_keys) a.out_keys[q * a.k + e] = KEY_NONE;
-                }
-            }
-        }
+        if (p == 0) a.tauq[q] = KEY_NONE;        // running bound of the query
         int nk = a.nkeys[q];
         nk = nk < 0 ? 0 : (nk > a.P ? a.P : nk);
         if (p < nk) {
@@ -199,7 +171,7 @@ __global__ __launch_bounds__(256) void bplan_kernel(BArgs a, int stride) {
                     const int sz = a.offsets[lo + 1] - a.offsets[lo];
                     if (sz > 0) {
                         b = lo;
-                        atomicAdd(&a.bcount[lo], 1);
+                        atomicAdd(&a.bcount[a.cell_of ? a.cell_of[lo] : lo], 1);
                     }
                 }
             }
@@ -237,9 +209,9 @@ __device__ __forceinline__ int block_excl_scan(int v, int *wsum, int *total) {
 // Numbering is deterministic: bcount_kernel leaves per-block totals, bscan_kernel sums the totals of the
 // blocks before it (no atomics, no dependence on block timing).
 __device__ __forceinline__ void bucket_task_counts(const BArgs &a, int i, int &b, int &m, int &s, int &ns, int &ng) {
-    b = a.border ? a.border[i] : i;
+    b = a.border ? a.border[i] : i;   // a CELL (a bucket when the index has no cells)
     m = a.bcount[b];
-    s = a.offsets[b + 1] - a.offsets[b];
+    s = a.coffsets[b + 1] - a.coffsets[b];
     ns = (s + a.seg - 1) / a.seg;
     ng = (m + a.QB - 1) / a.QB;
 }
@@ -248,7 +220,7 @@ __global__ __launch_bounds__(256) void bcount_kernel(BArgs a) {
     __shared__ int wsum[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
     int b, m = 0, s, ns = 0, ng = 0;
-    if (i < a.nb) bucket_task_counts(a, i, b, m, s, ns, ng);
+    if (i < a.nc) bucket_task_counts(a, i, b, m, s, ns, ng);
     int tot_m, tot_t, tot_neg;
     block_excl_scan(m, wsum, &tot_m);
     block_excl_scan(ng * ns, wsum, &tot_t);
@@ -286,7 +258,7 @@ __global__ __launch_bounds__(256) void bscan_kernel(BArgs a, int plan_blocks) {
     const bool bad = chk_s != 0 || neg_s != 0;
     int dummy;
     int b = 0, m = 0, s = 0, ns = 0, ng = 0;
-    if (i < a.nb) {
+    if (i < a.nc) {
         bucket_task_counts(a, i, b, m, s, ns, ng);
         if (bad) { m = 0; ng = 0; }
         a.bgroups[b] = ng;
@@ -320,7 +292,7 @@ __global__ __launch_bounds__(256) void bscan_kernel(BArgs a, int plan_blocks) {
     __shared__ int heavy_b[HEAVY_SLOTS][6];   // po, to, ng, nt, m, bucket (row0 and size are re-read)
     if (threadIdx.x == 0) heavy_n = 0;
     __syncthreads();
-    if (i < a.nb && !bad) {
+    if (i < a.nc && !bad) {
         const int po = base_m + ex_m, to = base_t + ex_t;
         a.pairoff[b] = po;
         a.taskoff[b] = to;
@@ -328,7 +300,7 @@ __global__ __launch_bounds__(256) void bscan_kernel(BArgs a, int plan_blocks) {
             const int slot = atomicAdd(&heavy_n, 1);   // <= 256 threads, so a slot always exists
             heavy_b[slot][0] = po; heavy_b[slot][1] = to; heavy_b[slot][2] = ng; heavy_b[slot][3] = nt; heavy_b[slot][4] = m; heavy_b[slot][5] = b;
         } else {
-            const int row0 = a.offsets[b];
+            const int row0 = a.coffsets[b];
             for (int t = 0; t < nt; ++t) {
                 const long long tt = (long long)to + t;
                 if (tt >= a.max_tasks) break;
@@ -342,7 +314,7 @@ __global__ __launch_bounds__(256) void bscan_kernel(BArgs a, int plan_blocks) {
     __syncthreads();
     for (int h = 0; h < heavy_n; ++h) {
         const int po = heavy_b[h][0], to = heavy_b[h][1], hng = heavy_b[h][2], hnt = heavy_b[h][3], hm = heavy_b[h][4], hb = heavy_b[h][5];
-        const int row0 = a.offsets[hb], hs = a.offsets[hb + 1] - row0;
+        const int row0 = a.coffsets[hb], hs = a.coffsets[hb + 1] - row0;
         for (int t = threadIdx.x; t < hnt; t += 256) {
             const long long tt = (long long)to + t;
             if (tt >= a.max_tasks) break;
@@ -360,26 +332,33 @@ __global__ __launch_bounds__(256) void bscatter_kernel(BArgs a) {
         a.prec[idx] = make_int4(0, 0, 0, 0);
         return;
     }
-    const int rel = atomicSub(&a.bcount[b], 1) - 1;  // slot of this query in the bucket's pair list
+    const int c = a.cell_of ? a.cell_of[b] : b;
+    const int rel = atomicSub(&a.bcount[c], 1) - 1;  // slot of this query in the cell's pair list
     if (rel < 0) {   // the counter started below zero-plus-this-batch's-pairs: a stale negative count (workspace contract); no slot exists
         a.status[1] = 2;
         a.prec[idx] = make_int4(0, 0, 0, 0);
         return;
     }
-    a.inv_q[a.pairoff[b] + rel] = (int32_t)(idx / a.P);
+    a.inv_q[a.pairoff[c] + rel] = (int32_t)(idx / a.P);
     // what bmerge needs to find this probe's partial lists, resolved here so that it has one load level less:
     // task of (segment si, group gi) = taskoff + si * ngroups + gi
     const int gi = rel / a.QB;
-    const int t0 = a.taskoff[b] + gi, size = a.offsets[b + 1] - a.offsets[b], ng = a.bgroups[b];
+    // `size` = rows of the BUCKET: the query's candidate count, and (size + seg - 1) / seg = its partial lists -- one per row segment of
+    // a big bucket, exactly one for a bucket inside a shared window (window_rows <= seg)
+    const int row0 = a.offsets[b], size = a.offsets[b + 1] - row0;
+    const int t0 = a.taskoff[c] + gi, ng = a.bgroups[c];
     a.prec[idx] = make_int4(t0, rel - gi * a.QB, size, ng);
-    if (a.merge_in_scan) atomicAdd(&a.remaining[idx / a.P], (size + a.seg - 1) / a.seg);   // one partial list per row segment of this probe
     if (a.task_q) {
         // the tiled scan reads a task's query ids from the task's own record (address known from the task id alone: the
         // ids arrive with the descriptor instead of one dependent round trip later); one copy per row segment
         const int ns = (size + a.seg - 1) / a.seg;
+        const int lo0 = row0 - a.coffsets[c];   // first row of the bucket inside its cell (0 for a bucket that is its own cell)
         for (int si = 0; si < ns; ++si) {
             const long long tt = (long long)t0 + (long long)si * ng;
-            if (tt < a.max_tasks) a.task_q[tt * a.QB + (rel - gi * a.QB)] = (int32_t)(idx / a.P);
+            if (tt >= a.max_tasks) break;
+            const int lo = max(lo0 - si * a.seg, 0), hi = min(lo0 + size - si * a.seg, a.seg);   // the bucket's rows inside segment si
+            a.task_q[tt * a.QB + (rel - gi * a.QB)] = (int32_t)(idx / a.P);
+            a.task_r[tt * a.QB + (rel - gi * a.QB)] = lo | (hi << 16);
         }
     }
 }
@@ -840,7 +819,6 @@ __device__ __forceinline__ void warm_query_lines_done(float &sink) {
 #endif
 }
 
-#if !NLSH_TILED_GLDS
 // All k-blocks of one L2 task for a wave that holds NQ (0..4) of its queries, NTL = tiles of the task (1..4): staging
 // (global -> registers -> LDS, next k-block's loads in flight during the current one) + the hand-scheduled k-blocks.
 // The (NQ, NTL) pair is chosen ONCE per task, outside the k-block loop: chosen per k-block, the 16 accumulators crossed
@@ -859,13 +837,15 @@ __device__ __forceinline__ void l2_task(float4 *tile, const float4 *corpus4, lon
     // Rows past the end of the segment and chunks past the end of a row are CLAMPED, not zero-filled: the clamped loads read valid
     // memory, rows >= nrows are masked at the epilogue (`valid`) and a k-block only evaluates its `nchunk` real chunks.  Guarded,
     // every staged word sat behind its own exec mask + branch + zero fill: ~22 VALU, 12 SALU and 4 branches per stage and wave.
+    // (r04: a SECOND register set -- two k-blocks of a wave's rows in flight, for the waves that hold <= 0 / 1 / 2 / 4 of the task's
+    // queries -- measured equal on all three workloads at 76 / 80 VGPRs and 3-6 % slower at 88: DESIGN.md appendix A.)
     const float4 *rowp[SPT];
 #pragma unroll
     for (int i = 0; i < SPT; ++i) rowp[i] = corpus4 + (long long)(row0 + min(sr + RPPt * i, nrows - 1)) * stride4;
     auto stage_load = [&](int kb) {
         const int gc = min(kb * KBt + sc, d4 - 1);
 #pragma unroll
-        for (int i = 0; i < SPT; ++i) stg[i] = NLSH_ABLATE != 2 ? rowp[i][gc] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < SPT; ++i) stg[i] = (NLSH_ABLATE != 2 && NLSH_ABLATE != 12 && NLSH_ABLATE != 13) ? rowp[i][gc] : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     stage_load(0);
     float qsink = 0.0f;
@@ -883,7 +863,7 @@ __device__ __forceinline__ void l2_task(float4 *tile, const float4 *corpus4, lon
         tr[0] += tb - ta;   // first barrier: the slowest wave's previous k-block
         tr[1] += tc - tb;   // own stage data (vmcnt) + LDS write + second barrier
         if (NQ > 0) warm_query_lines_done(qsink);   // behind the two barriers: the lines of this k-block are in the scalar cache
-        if (NQ > 0 && NLSH_ABLATE != 1 && NLSH_ABLATE != 6) {
+        if (NQ > 0 && NLSH_ABLATE != 1 && NLSH_ABLATE != 6 && NLSH_ABLATE != 13) {
             const int nchunk = min(KBt, d4 - kb * KBt);
             const_f32p qk[4];
 #pragma unroll
@@ -903,181 +883,6 @@ __device__ __forceinline__ void l2_task(float4 *tile, const float4 *corpus4, lon
     // released on EVERY path into the epilogue, whatever a future compiler makes of the loop.
     if (NQ > 0) warm_query_lines_done(qsink);
 }
-#endif  // !NLSH_TILED_GLDS
-
-#if NLSH_TILED_GLDS
-// ---- LDS-DMA staging (r03) ------------------------------------------------------------------------------------------------
-// The tile is an UNPADDED image of KBT 16-byte slots per row, two buffers of 256*KB slots.  A `global_load_lds_dwordx4` wave-
-// instruction writes 64 consecutive slots (wave-uniform base + lane * 16) while every lane supplies its own SOURCE address,
-// so the image is swizzled on the source side: slot p of row r holds chunk p ^ s(r), s(r) = (r >> (4 - log2 KBT)) & (KBT - 1).
-// Column reads (lane = row, ds_read_b128 is serviced in four groups of 16 lanes that are distinct mod 16, MI355X_MICROARCH.md
-// LDS table) then hit 16 distinct 16-byte bank groups: row stride 2^b slots contributes the low 4 - b bits of the row, the
-// swizzle the high b bits.  The 4 lanes that cover 64 contiguous bytes of a row still do (permuted): coalescing is unchanged.
-// s(r) only depends on the lane (r = tile * 64 + lane and only bits < 4 enter), so a lane's KBT slot offsets are constants of
-// the task: with the chunk loop fully unrolled a read costs no address arithmetic (tile offset = immediate, buffer = one XOR per
-// k-block and offset).
-// One k-block = { s_waitcnt vmcnt(0): my pieces of stage kb have landed; s_barrier: everybody's have, and everybody has finished
-// reading the other buffer; issue the DMA of stage kb + 1 into the other buffer; compute kb }.  RAW: the readers pass a barrier
-// after the issuing waves' vmcnt(0); WAR: the other buffer's last ds_read was retired (lgkmcnt(0) at the end of every k-block)
-// before the barrier that precedes its refill (cdna_hip_programming.md, "Read a staged buffer one phase AFTER the wait").
-template <int KBT>
-__device__ __forceinline__ constexpr int log2_kbt() { return KBT == 2 ? 1 : (KBT == 4 ? 2 : (KBT == 8 ? 3 : 4)); }
-
-__device__ __forceinline__ float4 lds_read16(const char *tile_bytes, unsigned off) {
-    return *reinterpret_cast<const float4 *>(tile_bytes + off);
-}
-
-// One k-block from LDS offsets `a[c]` (byte offset of this lane's slot of chunk c, tile 0, current buffer).  Blocks = (chunk,
-// tile) pairs in chunk-major order exactly like l2_kblock: row chunk of block j + 1 requested during block j, query chunk c + 1
-// requested during the first block of chunk c, prefetches past the end clamped.  FULL: nchunk == KBT, every index compile-time.
-template <int NQ, int NT, int KBT, int METRIC, bool FULL>
-__device__ __forceinline__ void kblock_glds(const char *tile_bytes, const unsigned (&a)[KBT], int nchunk, const const_f32p (&qk)[4], float (&acc)[4][4]) {
-    constexpr bool COS = METRIC == NLSH_METRIC_COSINE;
-    constexpr unsigned TSB = 64u * KBT * 16u;   // tile stride in bytes
-    QSet qa, qb;
-    float4 rr[2];
-    auto tile_block = [&](float (&ac)[4], const float4 r, const QSet &q) {
-        if (COS) cos_tile_block<NQ>(ac, r, q);
-        else if (METRIC == NLSH_METRIC_L2_EPS_FOLDED) l2f_tile_block<NQ>(ac, r, q);
-        else l2_tile_block<NQ>(ac, r, q);
-    };
-    if (FULL) {
-        rr[0] = lds_read16(tile_bytes, a[0]);
-        load_qset<NQ>(qa, qk, 0, 0.0f);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < KBT * NT; ++j) {
-            const int tl = j % NT, c = j / NT;
-            const int jn = (j + 1 < KBT * NT) ? j + 1 : j, tn = jn % NT, cn = jn / NT;   // the last block re-reads itself (value unused)
-            rr[(j + 1) & 1] = lds_read16(tile_bytes, a[cn] + tn * TSB);
-            if (tl == 0) {
-                const int cq = (c + 1 < KBT) ? c + 1 : c;
-                if ((c & 1) == 0) load_qset<NQ>(qb, qk, 16 * cq, rr[j & 1].x);
-                else load_qset<NQ>(qa, qk, 16 * cq, rr[j & 1].x);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            tile_block(acc[tl], rr[j & 1], (c & 1) ? qb : qa);
-            if (tl == NT - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the next chunk's queries (and first row chunk)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else {   // the row's last, partial k-block (d / 4 not a multiple of KBT): one chunk at a time, slot offset computed at run time
-        for (int c = 0; c < nchunk; ++c) {
-            load_qset<NQ>(qa, qk, 16 * c, 0.0f);
-            const unsigned off = a[0] ^ ((unsigned)c << 4);   // a[c] = row base + ((c ^ s) << 4) = a[0] ^ (c << 4)
-            rr[0] = lds_read16(tile_bytes, off);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int tl = 0; tl < NT; ++tl) {
-                if (tl + 1 < NT) rr[(tl + 1) & 1] = lds_read16(tile_bytes, off + (tl + 1) * TSB);
-                __builtin_amdgcn_sched_barrier(0);
-                tile_block(acc[tl], rr[tl & 1], qa);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-}
-
-template <int NW, int NQ, int NTL, int METRIC = NLSH_METRIC_L2_EPS>
-__device__ __forceinline__ void l2_task(float4 *tile, const float4 *corpus4, long long stride4, int d4, int row0, int nrows,
-                                        const const_f32p (&qs)[4], int tid, int lane, float (&acc)[4][4],
-                                        [[maybe_unused]] unsigned long long (&tr)[3]) {
-    constexpr int KB = NLSH_TILED_KB;
-    static_assert(NW == 4 && (KB == 2 || KB == 4), "LDS-DMA staging: 256-thread workgroups, 2 or 4 chunks per k-block");
-    constexpr int kshift = NLSH_FAT_STAGES ? (NTL <= 1 ? 2 : (NTL == 2 ? 1 : 0)) : 0;
-    constexpr int KBT = KB << kshift, BK = log2_kbt<KBT>();
-    constexpr unsigned BUF = 256u * KB * 16u;            // bytes per buffer (a power of two: the buffer toggle is one XOR)
-    const int nkb = (d4 + KBT - 1) / KBT;
-    char *tile_bytes = reinterpret_cast<char *>(tile);
-    // ---- fill side: piece i of this thread is slot g = i * 256 + tid of the stage: row g >> BK, slot position g & (KBT - 1)
-    const int pos = tid & (KBT - 1);
-    const int sw_fill = ((tid >> BK) >> (4 - BK)) & (KBT - 1);     // s(row): the same for all of a thread's pieces (rows 256 >> BK apart)
-    const int cfill = pos ^ sw_fill;                               // chunk (within the k-block) this thread fetches
-    const float4 *rowp[KB];
-#pragma unroll
-    for (int i = 0; i < KB; ++i) rowp[i] = corpus4 + (long long)(row0 + min(((i * 256 + tid) >> BK), nrows - 1)) * stride4;
-    const int wave = tid >> 6;
-    // The DMA is issued from inline asm: through the builtin the compiler knows that LDS is being written asynchronously and puts an
-    // `s_waitcnt vmcnt(0)` in front of the next LDS read -- i.e. directly behind the issue, which serialises the stage with the
-    // k-block it was meant to run under (first build of this path: 0.31 ms against 0.276).  In asm the pieces are outside hipcc's
-    // bookkeeping; their completion is the explicit vmcnt(0) + barrier at the top of the next k-block.  M0 (LDS base of a piece)
-    // is written in the statement that uses it and restored (cdna_hip_programming.md, LDS-DMA recipe).
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)tile_bytes;   // LDS byte address of the tile
-    auto stage_dma = [&](int kb) {
-        const int gc = min(kb * KBT + cfill, d4 - 1);              // chunks past the row end are clamped (never evaluated)
-        const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds0 + (kb & 1) * BUF + wave * 1024u);
-        if (NLSH_ABLATE == 2) return;
-        unsigned keep;
-        if (KB == 4) {
-            const float4 *g0 = rowp[0] + gc, *g1 = rowp[1] + gc, *g2 = rowp[KB > 2 ? 2 : 0] + gc, *g3 = rowp[KB > 2 ? 3 : 0] + gc;
-            asm volatile("s_mov_b32 %[keep], m0\n\t"
-                         "s_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[g0], off\n\t"
-                         "s_add_u32 m0, %[d], 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[g1], off\n\t"
-                         "s_add_u32 m0, %[d], 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[g2], off\n\t"
-                         "s_add_u32 m0, %[d], 0x3000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[g3], off\n\t"
-                         "s_mov_b32 m0, %[keep]"
-                         : [keep] "=&s"(keep) : [d] "s"(dst0), [g0] "v"(g0), [g1] "v"(g1), [g2] "v"(g2), [g3] "v"(g3) : "memory", "scc");
-        } else {
-            const float4 *g0 = rowp[0] + gc, *g1 = rowp[1] + gc;
-            asm volatile("s_mov_b32 %[keep], m0\n\t"
-                         "s_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[g0], off\n\t"
-                         "s_add_u32 m0, %[d], 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[g1], off\n\t"
-                         "s_mov_b32 m0, %[keep]"
-                         : [keep] "=&s"(keep) : [d] "s"(dst0), [g0] "v"(g0), [g1] "v"(g1) : "memory", "scc");
-        }
-    };
-    // ---- read side: byte offsets of this lane's slots (tile 0, buffer 0)
-    const unsigned sw_read = ((unsigned)lane >> (4 - BK)) & (KBT - 1);
-    unsigned a[KBT];
-#pragma unroll
-    for (int c = 0; c < KBT; ++c) a[c] = (unsigned)lane * (KBT * 16u) + (((unsigned)c ^ sw_read) << 4);
-    stage_dma(0);
-    float qsink = 0.0f;
-    asm volatile("" : "+s"(qsink));
-    if (NQ > 0) warm_query_lines<(NQ > 0 ? NQ : 1)>(qs, 0, min(KBT, d4) * 16, qsink);
-    // full k-blocks in the loop (every index of their body is a compile-time constant), the row's last partial one -- if d / 4 is not a
-    // multiple of KBT -- once behind it: no branch between two forms of the body inside the loop
-    const int nkb_full = d4 / KBT;
-    auto kblock_head = [&](int kb) {
-        [[maybe_unused]] const unsigned long long ta = SCAN_NOW();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // my pieces of stage kb are in LDS
-        __builtin_amdgcn_s_barrier();                          // ... and everybody's; the other buffer is free
-        [[maybe_unused]] const unsigned long long tb = SCAN_NOW();
-        if (kb + 1 < nkb) stage_dma(kb + 1);
-        tr[0] += tb - ta;
-        tr[1] += SCAN_NOW() - tb;
-        if (NQ > 0) warm_query_lines_done(qsink);
-    };
-    for (int kb = 0; kb < nkb_full; ++kb) {
-        kblock_head(kb);
-        [[maybe_unused]] const unsigned long long tc = SCAN_NOW();
-        if (NQ > 0 && NLSH_ABLATE != 1 && NLSH_ABLATE != 6) {
-            const_f32p qk[4];
-#pragma unroll
-            for (int jq = 0; jq < 4; ++jq) qk[jq] = qs[jq] + kb * KBT * 4;
-            kblock_glds<(NQ > 0 ? NQ : 1), NTL, KBT, METRIC, true>(tile_bytes, a, KBT, qk, acc);
-            if (kb + 1 < nkb) warm_query_lines<(NQ > 0 ? NQ : 1)>(qs, (kb + 1) * KBT * 16, min((kb + 2) * KBT, d4) * 16, qsink);
-#ifdef NLSH_SCAN_TRACE
-            asm volatile("" : "+v"(acc[0][0]));
-            tr[2] += SCAN_NOW() - tc;
-#endif
-        }
-#pragma unroll
-        for (int c = 0; c < KBT; ++c) a[c] ^= BUF;             // the next k-block reads the other buffer
-    }
-    if (nkb_full < nkb) {
-        kblock_head(nkb_full);
-        if (NQ > 0 && NLSH_ABLATE != 1 && NLSH_ABLATE != 6) {
-            const_f32p qk[4];
-#pragma unroll
-            for (int jq = 0; jq < 4; ++jq) qk[jq] = qs[jq] + nkb_full * KBT * 4;
-            kblock_glds<(NQ > 0 ? NQ : 1), NTL, KBT, METRIC, false>(tile_bytes, a, d4 - nkb_full * KBT, qk, acc);
-        }
-    }
-    if (NQ > 0) warm_query_lines_done(qsink);
-}
-#endif  // NLSH_TILED_GLDS
 
 template <int NW, int NQ, int METRIC = NLSH_METRIC_L2_EPS>
 __device__ __forceinline__ void l2_task_nt(int ntile, float4 *tile, const float4 *corpus4, long long stride4, int d4, int row0, int nrows,
@@ -1091,9 +896,6 @@ __device__ __forceinline__ void l2_task_nt(int ntile, float4 *tile, const float4
 }
 
 // Merge of ONE query's partial lists into its final top-k (one wavefront; `sc` = 64 u64 of LDS scratch owned by the wave).
-// AGENT: the lists were written inside the running launch by other workgroups (agent-scope stores, completed before the writer
-// took its count off the query's countdown): read them with agent-scope loads.
-template <bool AGENT>
 __device__ __forceinline__ void merge_query(const BArgs &a, long long q, int lane, uint64_t *sc) {
     int nk = __builtin_amdgcn_readfirstlane(a.nkeys[q]);
     nk = nk < 0 ? 0 : (nk > a.P ? a.P : nk);
@@ -1145,7 +947,7 @@ __device__ __forceinline__ void merge_query(const BArgs &a, long long q, int lan
             // t >= max_tasks: table overflow, status[1] was set by the scan kernel and the caller repeats the call
             const bool live = r < R && li < L && t < a.max_tasks;
             const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.partial) + ((live ? t : 0) * a.QB + j) * a.k + e;
-            key[s + 1] = !live ? KEY_NONE : (AGENT ? (uint64_t)__hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint64_t)*src);
+            key[s + 1] = live ? (uint64_t)*src : KEY_NONE;
         }
         carry = merge_round<4>(key, a.k, lane, sc);
     }
@@ -1161,7 +963,7 @@ __device__ __forceinline__ void merge_query(const BArgs &a, long long q, int lan
 // One task of the tiled schedule, start to finish (operands of the task already requested by the caller: descriptor and
 // the wave's query ids).  `tile` = the workgroup's LDS stage.
 template <int METRIC, int QW, int NW, int TPS>
-__device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, [[maybe_unused]] uint64_t *mscratch, long long t, const int4 desc, const int (&qid_v)[QW], int tid, int lane,
+__device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, long long t, const int4 desc, const int (&qid_v)[QW], const int (&rng_v)[QW], int tid, int lane,
                                                 int wave, [[maybe_unused]] unsigned long long ts_entry) {
     constexpr int NT = 64 * NW;              // threads per workgroup
     constexpr int KB = NLSH_TILED_KB;        // 16-byte chunks per k-block
@@ -1215,7 +1017,7 @@ __device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, [[
     auto stage_load = [&](int kb) {
         const int gc = min(kb * KBt + sc, d4 - 1);
 #pragma unroll
-        for (int i = 0; i < SPT; ++i) stg[i] = NLSH_ABLATE != 2 ? rowp[i][gc] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < SPT; ++i) stg[i] = (NLSH_ABLATE != 2 && NLSH_ABLATE != 12 && NLSH_ABLATE != 13) ? rowp[i][gc] : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     float acc[TPS][QW];
 #pragma unroll
@@ -1293,7 +1095,7 @@ __device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, [[
     }
     [[maybe_unused]] const unsigned long long ts2 = SCAN_NOW();
     if (nqw == 0) return;
-    if (NLSH_ABLATE == 5 || NLSH_ABLATE == 6) {   // diagnostic: no epilogue at all (the accumulators are kept alive)
+    if (NLSH_ABLATE == 5 || NLSH_ABLATE == 6 || NLSH_ABLATE == 12 || NLSH_ABLATE == 13) {   // diagnostic: no epilogue at all (the accumulators are kept alive)
 #pragma unroll
         for (int tl = 0; tl < TPS; ++tl)
 #pragma unroll
@@ -1315,11 +1117,17 @@ __device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, [[
     for (int jq = 0; jq < QW; ++jq) {
         if (jq < nqw) {
             const uint64_t tau_g = tau_w[jq];
+            // rows of the task that belong to THIS query's bucket: all of them for a segment of a big bucket, the bucket's slice of a
+            // window shared by several small buckets (the other rows were scored for nothing: the arithmetic of a shared window is what
+            // a task of its own would have cost each of those buckets in fixed latency)
+            const int rng = __builtin_amdgcn_readfirstlane(rng_v[jq]);
+            const unsigned r_lo = (unsigned)(rng & 0xFFFF), r_n = (unsigned)(rng >> 16) - r_lo;
             uint64_t key[TPS];
 #pragma unroll
             for (int tl = 0; tl < TPS; ++tl) {
                 const float dist = finish_distance<METRIC>(acc[tl][jq], myinv[tl]);
-                const uint64_t kk = valid[tl] ? make_key(dist, mygid[tl]) : KEY_NONE;
+                const bool mine = valid[tl] && (unsigned)(tl * 64 + lane) - r_lo < r_n;
+                const uint64_t kk = mine ? make_key(dist, mygid[tl]) : KEY_NONE;
                 key[tl] = kk < tau_g ? kk : KEY_NONE;  // beyond another list's k-th best: cannot reach the final top-k
             }
             uint64_t *out = a.partial + ((long long)t * (QW * NW) + NLSH_SLOT(wave, jq)) * a.k;
@@ -1340,36 +1148,11 @@ __device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, [[
             }
 #endif
             if (NLSH_ABLATE != 3) {
-                const uint64_t bound = select_k_smallest<TPS, false, NLSH_MERGE_IN_SCAN != 0>(key, a.k, lane, out);
+                const uint64_t bound = select_k_smallest<TPS>(key, a.k, lane, out);
                 if (bound != KEY_NONE && lane == 0) atomicMin(a.tauq + qid[jq], (unsigned long long)bound);
             } else if (lane < a.k) out[lane] = key[0];
         }
     }
-#if NLSH_MERGE_IN_SCAN
-    // The wave's lists are on their way to memory (agent-scope stores).  Once they are acknowledged, each takes one off its query's
-    // countdown; the list that takes the LAST one merges the query here and now (every other list of the query was acknowledged
-    // before its writer decremented, and is read with agent-scope loads): the merged result does not depend on who merges.
-    if (NLSH_ABLATE != 3) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        int left[QW];
-#pragma unroll
-        for (int jq = 0; jq < QW; ++jq) {
-            left[jq] = 0;
-            if (jq < nqw && lane == 0) left[jq] = __hip_atomic_fetch_add(a.remaining + qid[jq], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        int last = 0;
-#pragma unroll
-        for (int jq = 0; jq < QW; ++jq) last |= (jq < nqw && __builtin_amdgcn_readfirstlane(left[jq]) == 1) ? (1 << jq) : 0;
-        if (last) {
-#pragma nounroll
-            for (int jq = 0; jq < QW; ++jq) {
-                if (!((last >> jq) & 1)) continue;
-                const int qm = jq == 0 ? qid[0] : (jq == 1 ? qid[1] : (jq == 2 ? qid[2] : qid[QW - 1]));
-                merge_query<true>(a, qm, lane, mscratch + wave * 64);
-            }
-        }
-    }
-#endif
 #ifdef NLSH_SCAN_TRACE
     if (tid == 0 && t < NLSH_TRACE_SLOTS) {
         const unsigned long long ts4 = SCAN_NOW();
@@ -1397,12 +1180,7 @@ __global__ __launch_bounds__(64 * NW, NLSH_TILED_MIN_WAVES) void bscan3_kernel(B
     constexpr int ROWS = 64 * TPS;
     constexpr int SPT = ROWS * KB / NT;      // staged 16-byte words per thread and stage
     constexpr int RPP = NT / KB;             // rows covered by one pass of the workgroup
-#if NLSH_TILED_GLDS
-    __shared__ float4 tile[2 * ROWS * KB];   // two unpadded, swizzled buffers (LDS-DMA staging)
-    static_assert(NLSH_FAST_KBLOCK && NLSH_FAST_COSINE && QW == 4 && TPS == 4 && NW == 4, "LDS-DMA staging exists for the hand-scheduled task bodies only");
-#else
     __shared__ float4 tile[ROWS * RS];
-#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     [[maybe_unused]] const unsigned long long ts_entry = SCAN_NOW();
     if (NLSH_PRIO_OUT >= 0) __builtin_amdgcn_s_setprio(NLSH_PRIO_OUT);
@@ -1427,19 +1205,14 @@ __global__ __launch_bounds__(64 * NW, NLSH_TILED_MIN_WAVES) void bscan3_kernel(B
 #pragma unroll
     for (int jq = 0; jq < QW; ++jq)   // slots >= nq hold garbage, never used; clamped into [0, Q) so that a slot a stale counter invented (bmerge flags it) addresses nothing outside the queries
         qid_v[jq] = min(max(a.task_q[tc * (QW * NW) + NLSH_SLOT(wave, jq)], 0), (int)a.Q - 1);
+    int rng_v[QW];                                    // and each query's row range inside the task's rows
+#pragma unroll
+    for (int jq = 0; jq < QW; ++jq) rng_v[jq] = a.task_r[tc * (QW * NW) + NLSH_SLOT(wave, jq)];
     if (t >= ntasks) return;
     if (NLSH_ABLATE == 9) return;   // diagnostic: every workgroup leaves after its descriptor loads (what dispatching the grid costs)
     if (NLSH_ABLATE == 8 && desc.y <= NLSH_ABLATE_NQ) return;   // diagnostic: tasks with few queries vanish (what the low-density tasks cost)
     if (NLSH_ABLATE == 7 && desc.w <= 64) return;   // diagnostic: tasks of <= 64 rows vanish (what a kernel without the tail of tiny tasks would take)
-#if NLSH_MERGE_IN_SCAN
-    __shared__ uint64_t mscratch[NW * 64];   // per-wave scratch of the in-scan merge (the tile may still be read by slower waves)
-    // the workspace-contract check bmerge_kernel carries otherwise (see there): every pair counter is back at zero after the scatter
-    for (long long b = (long long)blockIdx.x * NT + tid; b < a.nb; b += (long long)gridDim.x * NT)
-        if (a.bcount[b] != 0) a.status[1] = 2;
-#else
-    uint64_t *mscratch = nullptr;
-#endif
-    tiled_task_body<METRIC, QW, NW, TPS>(a, tile, mscratch, t, desc, qid_v, tid, lane, wave, ts_entry);
+    tiled_task_body<METRIC, QW, NW, TPS>(a, tile, t, desc, qid_v, rng_v, tid, lane, wave, ts_entry);
 }
 
 __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
@@ -1447,14 +1220,14 @@ __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
     // contract).  The PLAN phase's sum check catches stale counts that change the totals (those would overrun the pair
     // lists); this per-bucket check catches the rest (stale counts that cancel in the sum mis-size individual lists: every
     // access stays in bounds -- clamped query ids, guarded slots -- but the lists are wrong), so a violated contract is
-    // ALWAYS reported (status[1] = 2), never a silently wrong result.  (With NLSH_MERGE_IN_SCAN the tiled scan does this check.)
+    // ALWAYS reported (status[1] = 2), never a silently wrong result.
     for (long long b = (long long)blockIdx.x * 256 + threadIdx.x; b < a.nb; b += (long long)gridDim.x * 256)
         if (a.bcount[b] != 0) a.status[1] = 2;
     const int lane = threadIdx.x & 63;
     const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= a.Q) return;
     __shared__ uint64_t scratch[4][64];
-    merge_query<false>(a, q, lane, scratch[threadIdx.x >> 6]);
+    merge_query(a, q, lane, scratch[threadIdx.x >> 6]);
 }
 
 #ifndef NLSH_TILED_QB
@@ -1467,7 +1240,7 @@ constexpr int TILED_QB = NLSH_TILED_QB;  // queries per task of the tiled schedu
 constexpr int TILED_TPS = NLSH_TILED_TPS;  // 64-row tiles per task of the tiled schedule (segment = 64*TPS rows)
 
 struct BWs {
-    size_t pbkt, prec, inv_q, bcount, pairoff, taskoff, bgroups, counters, btot, hits, remaining, task, task_q, partial, qpad, tauq, total;
+    size_t pbkt, prec, inv_q, bcount, pairoff, taskoff, bgroups, counters, btot, hits, task, task_q, task_r, partial, qpad, tauq, total;
 };
 static void blayout(long long Q, int P, int k, long long max_tasks, long long nb, int d, bool tiled, BWs *w) {
     size_t o = 0;
@@ -1482,9 +1255,9 @@ static void blayout(long long Q, int P, int k, long long max_tasks, long long nb
     w->counters = o; o += ws_align(64);
     w->btot = o;     o += ws_align((size_t)((nb + 255) / 256 + 1) * 12);
     w->hits = o;     o += ws_align((size_t)((Q * P + 255) / 256 + 1) * 4);
-    w->remaining = o; o += ws_align((size_t)(Q > 0 ? Q : 1) * 4);
     w->task = o;     o += ws_align((size_t)max_tasks * sizeof(int4));
     w->task_q = o;   o += tiled ? ws_align((size_t)max_tasks * TILED_QB * 4) : 0;
+    w->task_r = o;   o += tiled ? ws_align((size_t)max_tasks * TILED_QB * 4) : 0;
     w->partial = o;  o += ws_align((size_t)max_tasks * (tiled ? TILED_QB : 8) * k * 8);
     w->qpad = o;     o += tiled ? ws_align((size_t)Q * ((d + 3) / 4) * 16) : 0;
     w->tauq = o;     o += ws_align((size_t)Q * 8);
@@ -1501,13 +1274,14 @@ size_t bucket_scan_workspace(long long Q, int P, int k, long long max_tasks, lon
 }  // namespace nlsh
 
 extern "C" int nlsh_scan_workspace_layout(int64_t Q, int P, int k, int64_t max_tasks, int64_t n_buckets, int d, int algo,
-                                          size_t *task_table_offset, size_t *task_queries_offset) {
+                                          size_t *task_table_offset, size_t *task_queries_offset, size_t *task_ranges_offset) {
     NLSH_REQUIRE(algo == NLSH_SCAN_BUCKET_MAJOR || algo == NLSH_SCAN_BUCKET_TILED, NLSH_E_INVALID, "scan_workspace_layout: algo=%d has no task table of this form", algo);
     NLSH_REQUIRE(Q >= 0 && P >= 1 && k >= 1 && max_tasks >= 0 && n_buckets >= 0 && d >= 1, NLSH_E_INVALID, "scan_workspace_layout: bad sizes");
     nlsh::BWs w;
     nlsh::blayout(Q, P, k, max_tasks, n_buckets, d, algo == NLSH_SCAN_BUCKET_TILED, &w);
     if (task_table_offset) *task_table_offset = w.task;
     if (task_queries_offset) *task_queries_offset = w.task_q;
+    if (task_ranges_offset) *task_ranges_offset = w.task_r;
     return NLSH_OK;
 }
 
@@ -1529,6 +1303,9 @@ int bucket_scan_run(const BucketScanCall &c) {
     const int d4 = (c.d + 3) / 4;
     BArgs a;
     a.corpus = c.corpus; a.row_stride = c.row_stride; a.d = c.d; a.gid = c.gid; a.uniq = c.uniq; a.offsets = c.offsets; a.nb = c.nb;
+    // cells exist for the tiled schedule only (a window is one 256-row segment of its task shape); the wave-level schedule ignores them
+    const bool cells = c.tiled && c.cell_of && c.cell_offsets && c.n_cells > 0;
+    a.cell_of = cells ? c.cell_of : nullptr; a.coffsets = cells ? c.cell_offsets : c.offsets; a.nc = cells ? c.n_cells : c.nb;
     a.inv_norm = c.inv_norm; a.queries = c.queries; a.q_stride = c.q_stride; a.Q = c.Q; a.qkeys = c.qkeys; a.nkeys = c.nkeys;
     a.P = c.P; a.k = c.k; a.seg = c.tiled ? 64 * TILED_TPS : c.seg; a.QB = c.tiled ? TILED_QB : (d4 <= 64 ? 8 : (d4 <= 128 ? 4 : 2));
     a.qpad_w = (float *)((char *)c.workspace + w.qpad); a.qpad = a.qpad_w; a.qpad_stride = (long long)d4 * 4; a.d4p = d4;
@@ -1542,7 +1319,7 @@ int bucket_scan_run(const BucketScanCall &c) {
     char *base = (char *)c.workspace;
     a.pbkt = (int32_t *)(base + w.pbkt); a.prec = (int4 *)(base + w.prec); a.inv_q = (int32_t *)(base + w.inv_q);
     a.bcount = (int32_t *)(base + w.bcount); a.pairoff = (int32_t *)(base + w.pairoff); a.taskoff = (int32_t *)(base + w.taskoff); a.bgroups = (int32_t *)(base + w.bgroups);
-    a.counters = (int32_t *)(base + w.counters); a.btot = (int32_t *)(base + w.btot); a.hits = (int32_t *)(base + w.hits); a.remaining = (int32_t *)(base + w.remaining); a.merge_in_scan = (c.tiled && NLSH_MERGE_IN_SCAN) ? 1 : 0; a.border = c.bucket_order; a.task = (int4 *)(base + w.task); a.task_q = c.tiled ? (int32_t *)(base + w.task_q) : nullptr; a.partial = (uint64_t *)(base + w.partial);
+    a.counters = (int32_t *)(base + w.counters); a.btot = (int32_t *)(base + w.btot); a.hits = (int32_t *)(base + w.hits); a.border = c.bucket_order; a.task = (int4 *)(base + w.task); a.task_q = c.tiled ? (int32_t *)(base + w.task_q) : nullptr; a.task_r = c.tiled ? (int32_t *)(base + w.task_r) : nullptr; a.partial = (uint64_t *)(base + w.partial);
     a.max_tasks = c.max_tasks;
     a.tauq = (unsigned long long *)(base + w.tauq);
 
@@ -1560,8 +1337,8 @@ int bucket_scan_run(const BucketScanCall &c) {
         // (r03: bcount + bscan as ONE single-workgroup launch for indexes of <= 8192 buckets -- strided bucket map, counts and prefixes
         // through 64 KB of LDS, all loads of a thread's 8 buckets issued together -- took 23 us against 16.4 us for the two launches
         // below (33 us before the loads were batched): one CU writes 12 k task descriptors slower than 23 workgroups do.)
-        if (c.nb > 0) {
-            const unsigned gb = (unsigned)((c.nb + 255) / 256);
+        if (a.nc > 0) {
+            const unsigned gb = (unsigned)((a.nc + 255) / 256);
             hipLaunchKernelGGL(bcount_kernel, dim3(gb), dim3(256), 0, s, a);
             hipLaunchKernelGGL(bscan_kernel, dim3(gb), dim3(256), 0, s, a, (int)gp);
         }
@@ -1585,8 +1362,7 @@ int bucket_scan_run(const BucketScanCall &c) {
         }
         if (c.ev_end) NLSH_CHECK_HIP(hipEventRecord((hipEvent_t)c.ev_end, s));
     }
-    // (the tiled schedule with NLSH_MERGE_IN_SCAN has merged every query inside its scan launch: nothing to do here)
-    if ((c.phases & NLSH_PHASE_MERGE) && !a.merge_in_scan) hipLaunchKernelGGL(bmerge_kernel, dim3((unsigned)((c.Q + 3) / 4)), dim3(256), 0, s, a);
+    if (c.phases & NLSH_PHASE_MERGE) hipLaunchKernelGGL(bmerge_kernel, dim3((unsigned)((c.Q + 3) / 4)), dim3(256), 0, s, a);
     NLSH_CHECK_HIP(hipGetLastError());
     return NLSH_OK;
 }

@@ -2,6 +2,31 @@
 #pragma once
 #include "common.h"
 
+// Diagnostic timing builds (`make VARIANT=diag EXTRA="-DNLSH_DIAG -DNLSH_ABLATE=n"`, tools/scan_bench.py): every switch below
+// produces WRONG results by design (it removes a piece of the kernel to time the rest) and exists only under NLSH_DIAG, so that a
+// stray -D on the shipped build cannot turn one on.  NLSH_ABLATE: 1 no distance math, 2 no global loads, 3 no top-k selection,
+// 4 no scalar loads (generic loop), 5 no epilogue, 6 neither math nor epilogue (staging skeleton), 7 tasks of <= 64 rows vanish,
+// 8 tasks of <= NLSH_ABLATE_NQ queries vanish, 9 every workgroup leaves after its descriptor loads, 11 no bisection in the
+// selection, 12 = 2 + 5 (no global loads, no epilogue), 13 = 2 + 6 (barriers and LDS writes only).  NLSH_NO_STAGE_BARRIER=1: the stage barriers of the hand-scheduled task body are removed (the four waves of a
+// workgroup race on the tile): what the barriers' straggler coupling costs (r03: 3-5 %).
+// (Two r03 experiments lived here behind switches and were deleted in r04, measured slower and never shipped: LDS-DMA staging of the
+// k-blocks, NLSH_TILED_GLDS, and the per-query merge inside the scan launch, NLSH_MERGE_IN_SCAN.  DESIGN.md appendix A and
+// profiles/r03_glds_ab.txt / r03_merge_in_scan_ab.txt keep the findings; git history keeps the code.)
+#ifdef NLSH_DIAG
+#ifndef NLSH_ABLATE
+#define NLSH_ABLATE 0
+#endif
+#ifndef NLSH_NO_STAGE_BARRIER
+#define NLSH_NO_STAGE_BARRIER 0
+#endif
+#else
+#if defined(NLSH_ABLATE) || defined(NLSH_NO_STAGE_BARRIER)
+#error "NLSH_ABLATE / NLSH_NO_STAGE_BARRIER produce wrong results by design: diagnostic builds only (add -DNLSH_DIAG)"
+#endif
+#define NLSH_ABLATE 0
+#define NLSH_NO_STAGE_BARRIER 0
+#endif
+
 namespace nlsh {
 
 template <int CTRL>
@@ -111,9 +136,7 @@ __device__ __forceinline__ uint32_t wave_minmax_u32(uint32_t x) {
 // CLAMP (the merges): keys that reach a merge are distinct when every (query, bucket) pair was scanned once -- the plan
 // kernels de-duplicate a query's probe keys, corpus shards are disjoint -- but nlsh_merge_topk takes whatever lists a C
 // caller hands it: with repeated keys the tie search can select more than k, so the compaction never writes past out[k).
-// AGENT (the tiled scan's partial lists when the query's last list merges them inside the same launch, NLSH_MERGE_IN_SCAN): the k
-// survivors are written with agent-scope stores (sc1: written through, visible to the other XCDs' sc1 loads once acknowledged).
-template <int NK, bool CLAMP = false, bool AGENT = false>
+template <int NK, bool CLAMP = false>
 __device__ __forceinline__ uint64_t select_k_smallest(const uint64_t (&key)[NK], int k, int lane, uint64_t *out) {
     uint32_t hi[NK], lo[NK];
     int n = 0;
@@ -136,7 +159,7 @@ __device__ __forceinline__ uint64_t select_k_smallest(const uint64_t (&key)[NK],
         // invariants: #{hi <= b} >= k (b = max: all n > k keys) and #{hi < a} < k (a = min: none)
         bool split = false;
         if (n == k) { a = b; split = true; }   // all present keys are taken: the cut is the largest of them
-#if defined(NLSH_ABLATE) && NLSH_ABLATE == 11   // diagnostic timing build (WRONG results): no bisection at all -- what the search for the cut costs
+#if NLSH_ABLATE == 11   // diagnostic timing build (WRONG results): no bisection at all -- what the search for the cut costs
         a = b; split = true;
 #endif
         while (a < b) {
@@ -175,20 +198,16 @@ __device__ __forceinline__ uint64_t select_k_smallest(const uint64_t (&key)[NK],
         const bool sel = key[i] != KEY_NONE && (hi[i] < dk || (hi[i] == dk && lo[i] <= idk));
         const unsigned long long m = __ballot(sel);
         const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-#if defined(NLSH_ABLATE) && NLSH_ABLATE == 11
+#if NLSH_ABLATE == 11
         if (sel && pos < k) {
 #else
         if (sel && (!CLAMP || pos < k)) {
 #endif
-            if (AGENT) __hip_atomic_store(reinterpret_cast<unsigned long long *>(out) + pos, (unsigned long long)key[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else out[pos] = key[i];
+            out[pos] = key[i];
         }
         base += __popcll(m);
     }
-    if (lane >= base && lane < k) {
-        if (AGENT) __hip_atomic_store(reinterpret_cast<unsigned long long *>(out) + lane, (unsigned long long)KEY_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else out[lane] = KEY_NONE;
-    }
+    if (lane >= base && lane < k) out[lane] = KEY_NONE;
     return n >= k ? ((uint64_t)dk + 1ull) << 32 : KEY_NONE;
 }
 
@@ -288,8 +307,11 @@ struct BucketScanCall {
     const float *inv_norm; const float *queries; long long q_stride; long long Q; const int32_t *qkeys; const int32_t *nkeys;
     int P, k, metric, seg; float *out_dist; int32_t *out_idx; uint64_t *out_keys; int32_t *out_ncand; int32_t *status;
     void *workspace; size_t workspace_bytes; long long max_tasks; void *ev_begin; void *ev_end; hipStream_t stream; int tiled;
-    const int32_t *bucket_order;  // nlsh_bucket_order output or nullptr
-    int phases;                   // NLSH_PHASE_PLAN | NLSH_PHASE_SCAN
+    const int32_t *bucket_order;  // nlsh_bucket_order output (nlsh_build_cells' cell_order when cells are given) or nullptr
+    int phases;                   // NLSH_PHASE_PLAN | NLSH_PHASE_SCAN | NLSH_PHASE_MERGE
+    const int32_t *cell_of;       // nlsh_build_cells outputs, or nullptr / 0: every bucket is its own cell
+    const int32_t *cell_offsets;
+    int n_cells;
 };
 size_t bucket_scan_workspace(long long Q, int P, int k, long long max_tasks, long long n_buckets, int d);
 int bucket_scan_run(const BucketScanCall &c);

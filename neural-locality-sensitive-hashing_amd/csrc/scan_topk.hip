@@ -286,8 +286,9 @@ extern "C" size_t nlsh_scan_workspace(int64_t Q, int P, int k, int64_t max_tasks
     return w.total > b ? w.total : b;
 }
 
-extern "C" int nlsh_scan_topk_phase(const float *corpus_sorted, int64_t row_stride, int d, const int32_t *gid,
+extern "C" int nlsh_scan_topk_cells_phase(const float *corpus_sorted, int64_t row_stride, int d, const int32_t *gid,
                               const int32_t *uniq_keys, const int32_t *offsets, const int32_t *bucket_order, int32_t n_buckets,
+                              const int32_t *cell_of, const int32_t *cell_offsets, int32_t n_cells,
                               const float *inv_norm, const float *queries, int64_t q_stride, int64_t Q, const int32_t *qkeys, const int32_t *nkeys,
                               int P, int k, int metric, int algo, int seg_rows, float *out_dist, int32_t *out_idx,
                               uint64_t *out_keys, int32_t *out_ncand, int32_t *status, void *workspace, size_t workspace_bytes,
@@ -301,6 +302,8 @@ extern "C" int nlsh_scan_topk_phase(const float *corpus_sorted, int64_t row_stri
     NLSH_REQUIRE(algo == NLSH_SCAN_QUERY_MAJOR || algo == NLSH_SCAN_BUCKET_MAJOR || algo == NLSH_SCAN_BUCKET_TILED, NLSH_E_INVALID,
                  "scan_topk: algo=%d", algo);
     NLSH_REQUIRE(n_buckets >= 0 && max_tasks >= 0 && seg_rows >= 0, NLSH_E_INVALID, "scan_topk: negative size");
+    NLSH_REQUIRE(n_cells >= 0 && n_cells <= n_buckets && (n_cells == 0 || (cell_of && cell_offsets)), NLSH_E_INVALID,
+                 "scan_topk: n_cells=%d needs cell_of and cell_offsets and cannot exceed n_buckets=%d", (int)n_cells, (int)n_buckets);
     if (Q == 0) return NLSH_OK;
     NLSH_REQUIRE(queries && qkeys && nkeys && out_dist && out_idx && out_ncand && status && workspace, NLSH_E_INVALID, "scan_topk: null pointer");
     NLSH_REQUIRE(n_buckets == 0 || (corpus_sorted && gid && uniq_keys && offsets), NLSH_E_INVALID, "scan_topk: null index pointer");
@@ -315,7 +318,8 @@ extern "C" int nlsh_scan_topk_phase(const float *corpus_sorted, int64_t row_stri
     if (algo != NLSH_SCAN_QUERY_MAJOR) {
         BucketScanCall c = {corpus_sorted, row_stride, d, gid, uniq_keys, offsets, n_buckets, inv_norm, queries, q_stride, Q,
                             qkeys, nkeys, P, k, metric, seg_rows, out_dist, out_idx, out_keys, out_ncand, status, workspace,
-                            workspace_bytes, max_tasks, ev_scan_begin, ev_scan_end, s, algo == NLSH_SCAN_BUCKET_TILED, bucket_order, phases};
+                            workspace_bytes, max_tasks, ev_scan_begin, ev_scan_end, s, algo == NLSH_SCAN_BUCKET_TILED, bucket_order, phases,
+                            cell_of, cell_offsets, (int)n_cells};
         return bucket_scan_run(c);
     }
 
@@ -349,6 +353,17 @@ extern "C" int nlsh_scan_topk_phase(const float *corpus_sorted, int64_t row_stri
         hipLaunchKernelGGL(merge_segments_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, s, a);
     NLSH_CHECK_HIP(hipGetLastError());
     return NLSH_OK;
+}
+
+extern "C" int nlsh_scan_topk_phase(const float *corpus_sorted, int64_t row_stride, int d, const int32_t *gid,
+                              const int32_t *uniq_keys, const int32_t *offsets, const int32_t *bucket_order, int32_t n_buckets,
+                              const float *inv_norm, const float *queries, int64_t q_stride, int64_t Q, const int32_t *qkeys, const int32_t *nkeys,
+                              int P, int k, int metric, int algo, int seg_rows, float *out_dist, int32_t *out_idx,
+                              uint64_t *out_keys, int32_t *out_ncand, int32_t *status, void *workspace, size_t workspace_bytes,
+                              int64_t max_tasks, void *ev_scan_begin, void *ev_scan_end, nlsh_stream_t stream, int phases) {
+    return nlsh_scan_topk_cells_phase(corpus_sorted, row_stride, d, gid, uniq_keys, offsets, bucket_order, n_buckets, nullptr, nullptr, 0,
+                                      inv_norm, queries, q_stride, Q, qkeys, nkeys, P, k, metric, algo, seg_rows, out_dist, out_idx, out_keys,
+                                      out_ncand, status, workspace, workspace_bytes, max_tasks, ev_scan_begin, ev_scan_end, stream, phases);
 }
 
 extern "C" int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, int d, const int32_t *gid,

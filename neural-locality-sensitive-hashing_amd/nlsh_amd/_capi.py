@@ -21,12 +21,13 @@ PHASE_PLAN, PHASE_SCAN, PHASE_MERGE = 1, 2, 4
 PHASE_ALL = 7
 MAX_ENCODE_PROBES = 128  # nlsh_encode_hash generates up to this many keys per row; the scan takes them in slices of MAX_PROBES
 
-# every symbol include/nlsh_hip.h declares (tests/test_capi_symbols.py checks the header against this)
+# every symbol include/nlsh_hip.h declares (tests/test_host_cpu.py checks the header against this)
 SYMBOLS = (
     "nlsh_abi_version", "nlsh_last_error",
     "nlsh_encoder_packed_floats", "nlsh_encoder_pack", "nlsh_encode_hash", "nlsh_pack_codes",
-    "nlsh_build_csr_workspace", "nlsh_build_csr", "nlsh_bucket_order_workspace", "nlsh_bucket_order", "nlsh_gather_rows",
-    "nlsh_scan_workspace", "nlsh_scan_workspace_layout", "nlsh_scan_topk", "nlsh_scan_topk_phase", "nlsh_merge_topk",
+    "nlsh_build_csr_workspace", "nlsh_build_csr", "nlsh_bucket_order_workspace", "nlsh_bucket_order", "nlsh_build_cells_workspace", "nlsh_build_cells", "nlsh_gather_rows",
+    "nlsh_scan_workspace", "nlsh_scan_workspace_layout", "nlsh_scan_topk", "nlsh_scan_topk_phase", "nlsh_scan_topk_cells_phase",
+    "nlsh_merge_topk",
 )
 
 
@@ -75,17 +76,23 @@ def lib():
     L.nlsh_bucket_order_workspace.argtypes = [i64]
     L.nlsh_bucket_order.restype = i32
     L.nlsh_bucket_order.argtypes = [vp, i64, vp, vp, sz, vp]
+    L.nlsh_build_cells_workspace.restype = sz
+    L.nlsh_build_cells_workspace.argtypes = [i64]
+    L.nlsh_build_cells.restype = i32
+    L.nlsh_build_cells.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, sz, vp]
     L.nlsh_gather_rows.restype = i32
     L.nlsh_gather_rows.argtypes = [vp, i64, i32, vp, i64, vp, i64, vp, vp, ctypes.c_int32, vp]
     L.nlsh_scan_workspace.restype = sz
     L.nlsh_scan_workspace.argtypes = [i64, i32, i32, i64, i64, i32]
     L.nlsh_scan_workspace_layout.restype = i32
-    L.nlsh_scan_workspace_layout.argtypes = [i64, i32, i32, i64, i64, i32, i32, vp, vp]
+    L.nlsh_scan_workspace_layout.argtypes = [i64, i32, i32, i64, i64, i32, i32, vp, vp, vp]
     L.nlsh_scan_topk.restype = i32
     L.nlsh_scan_topk.argtypes = [vp, i64, i32, vp, vp, vp, vp, ctypes.c_int32, vp, vp, i64, i64, vp, vp, i32, i32, i32, i32, i32,
                                  vp, vp, vp, vp, vp, vp, sz, i64, vp, vp, vp]
     L.nlsh_scan_topk_phase.restype = i32
     L.nlsh_scan_topk_phase.argtypes = list(L.nlsh_scan_topk.argtypes) + [i32]
+    L.nlsh_scan_topk_cells_phase.restype = i32     # cell_of, cell_offsets, n_cells follow n_buckets
+    L.nlsh_scan_topk_cells_phase.argtypes = L.nlsh_scan_topk_phase.argtypes[:8] + [vp, vp, ctypes.c_int32] + L.nlsh_scan_topk_phase.argtypes[8:]
     L.nlsh_merge_topk.restype = i32
     L.nlsh_merge_topk.argtypes = [vp, i64, i32, i64, i32, vp, vp, vp, vp, vp]
     _lib = L

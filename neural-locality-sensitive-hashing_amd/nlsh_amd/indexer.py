@@ -108,7 +108,7 @@ class Indexer:
     def __init__(self, hashing, candidate_vectors_gpu, distance_func, compat=True, metric: Optional[str] = None,
                  seg_rows: int = 0, id_base: int = 0, algo: Optional[str] = None,
                  row_ids: Optional[torch.Tensor] = None, schedule_stats: Optional[Tuple[float, float]] = None,
-                 corpus_keys: Optional[torch.Tensor] = None, l2_form: str = "exact"):
+                 corpus_keys: Optional[torch.Tensor] = None, l2_form: str = "exact", window_rows: Optional[int] = None):
         self._hashing = hashing
         self._candidate_vectors_gpu = candidate_vectors_gpu
         self._distance_func = distance_func
@@ -133,6 +133,13 @@ class Indexer:
         if l2_form not in ("exact", "folded"):
             raise ValueError("l2_form must be 'exact' or 'folded'")
         self.l2_form = l2_form
+        # Small-bucket packing of the tiled schedule (include/nlsh_hip.h, nlsh_build_cells): consecutive buckets of <= window_rows rows
+        # share one row window and its tasks.  None = choose per batch (`choose_window`), 0 = off (one task list per bucket, r03),
+        # 64 / 128 / 256 = forced.  Never changes a result bit, only the number of tasks.
+        if window_rows is not None and not 0 <= int(window_rows) <= 256:
+            raise ValueError("window_rows must be None (auto) or in [0, 256]")
+        self.window_rows = None if window_rows is None else int(window_rows)
+        self._cells = {}            # window_rows -> (cell_of, cell_offsets, cell_order, n_cells), built on first use
         self._index2row = None
         self._perm_host = None
         self._e_sb = None
@@ -250,6 +257,47 @@ class Indexer:
             return _capi.SCAN_BUCKET_MAJOR
         return _capi.SCAN_QUERY_MAJOR
 
+    def cells(self, window_rows):
+        """(cell_of, cell_offsets, cell_order, n_cells) of this index for one window size: `nlsh_build_cells`, once per (index, size)."""
+        got = self._cells.get(window_rows)
+        if got is None:
+            L = _capi.lib()
+            dev, nb = self.offsets.device, self.n_buckets
+            cell_of = torch.empty((max(nb, 1),), dtype=torch.int32, device=dev)
+            cell_offsets = torch.empty((nb + 1,), dtype=torch.int32, device=dev)
+            cell_order = torch.empty((max(nb, 1),), dtype=torch.int32, device=dev)
+            n_cells = torch.zeros((1,), dtype=torch.int32, device=dev)
+            wb = L.nlsh_build_cells_workspace(nb)
+            if wb == 0 and nb:
+                _capi.check(_capi.E_HIP)
+            ws = torch.empty((max(wb, 1),), dtype=torch.uint8, device=dev)
+            _capi.check(L.nlsh_build_cells(_capi.ptr(self.offsets), nb, window_rows, _capi.ptr(cell_of), _capi.ptr(cell_offsets),
+                                           _capi.ptr(cell_order), _capi.ptr(n_cells), _capi.ptr(ws), wb, _stream(dev)))
+            nc = int(n_cells.item())    # like the bucket count of the index build: once per index, not on the query path
+            got = self._cells[window_rows] = (cell_of, cell_offsets[:nc + 1], cell_order[:max(nc, 1)], nc)
+        return got
+
+    def choose_window(self, Q, P, algo):
+        """Row window of the small-bucket packing for one batch shape (tiled schedule only): 64 rows unless forced.
+        Measured (r04, tools/scan_bench.py --window 0,64,128,256 --rounds 4, same process and keys, scan kernel ms, one box):
+            window            0       64      128     256
+            SIFT1M headline   0.2427  0.2400  0.2434  0.2522     (skewed 16-bit hash, 45 k pairs on 5.1 k probed buckets)
+            SIFT1M clusters   0.1613  0.1359  0.1377  0.1575     (SURVEY 8(d) generator, 49.7 k pairs on 18.1 k buckets)
+            GloVe-1.2M        0.1588  0.1231  0.1244  0.1497     (24-bit cosine, 64.7 k pairs on 36.6 k buckets)
+        A 64-row window adds no arithmetic (a lone small bucket already pays a whole 64-row tile and the fat single-tile stages)
+        and only merges tasks; wider windows score every row of the window for every query of the task, which the balanced
+        workloads earn back in task count up to 128 rows and the skewed headline does not.  One value keeps every shard count on
+        the same arithmetic-free choice (results never depend on it)."""
+        if algo != _capi.SCAN_BUCKET_TILED or self.n_buckets == 0:
+            return 0
+        if self.window_rows is not None:
+            return self.window_rows
+        return 64
+
+    def _tkey(self, algo, Q, P):
+        """Key of a batch shape's task table in `_max_tasks`: (schedule, Q, P, row window of the small-bucket packing)."""
+        return (algo, Q, P, self.choose_window(Q, P, algo))
+
     def _estimate_tasks(self, Q, P, seg, algo):
         biased = self._size_biased_bucket()
         if algo == _capi.SCAN_BUCKET_TILED:   # tasks = (256-row segment, <= 16 queries)
@@ -290,9 +338,10 @@ class Indexer:
             algo = self.choose_algo(Q, P)
         # the task table is sized per (schedule, batch shape): a larger batch after a smaller one re-estimates instead of
         # reusing a table that `check=False` callers would silently overflow
-        tkey = (algo, Q, P)
+        window = self.choose_window(Q, P, algo)
+        tkey = self._tkey(algo, Q, P)
         if tkey not in self._max_tasks:
-            grown = [v for (a_, q_, p_), v in self._max_tasks.items() if a_ == algo and q_ >= Q and p_ >= P]
+            grown = [v for (a_, q_, p_, w_), v in self._max_tasks.items() if a_ == algo and q_ >= Q and p_ >= P and w_ == window]
             self._max_tasks[tkey] = min(grown) if grown else self._estimate_tasks(Q, P, seg, algo)
         while True:
             max_tasks = self._max_tasks[tkey]
@@ -306,7 +355,7 @@ class Indexer:
                 ws = self._ws[wkey] = torch.zeros((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
             try:
                 self._scan_launch(q, keys, nkeys, k, algo, max_tasks, out_dist, out_idx, out_keys, ncand, status, ws,
-                                  _capi.PHASE_ALL, events)
+                                  _capi.PHASE_ALL, events, window)
             except _capi.NlshHipError:
                 self._ws.pop(wkey, None)    # a call that failed part-way may have left the counters at the head non-zero
                 raise
@@ -314,11 +363,15 @@ class Indexer:
                 break
             needed, overflow = status.cpu().tolist()
             if not overflow:
+                # the one-shot tiled kernel launches a workgroup per table slot: a table sized for the bucket-per-task estimate and
+                # then run with shared windows (a fifth of the tasks) is trimmed once the batch shape's real need is known
+                if 3 * (needed + 1024) < max_tasks:
+                    self._max_tasks[tkey] = int(needed * 1.25) + 1024
                 break
             self._grow_task_table(tkey, needed, overflow)           # segment table too small: grow and repeat
         self.last_status = status
-        self.last_algo = algo
-        self._last_pack, self._last_tkey = pack, tkey
+        self.last_algo, self.last_window = algo, window
+        self._last_pack, self._last_tkey, self._last_max_tasks = pack, tkey, max_tasks
         return out_dist, out_idx, ncand, out_keys
 
     def _grow_task_table(self, tkey, needed, flag=1):
@@ -331,23 +384,30 @@ class Indexer:
                                                         "were not zero on entry (workspace contract, include/nlsh_hip.h)")
         self._max_tasks[tkey] = int(needed * 1.25) + 1024
 
-    def _scan_args(self, Q, d, keys, nkeys, k, algo, max_tasks, out_dist, out_idx, out_keys, ncand, status, ws):
-        """The arguments of `nlsh_scan_topk_phase` that do not change between batches of one shape, as plain ints:
+    def _scan_args(self, Q, d, keys, nkeys, k, algo, max_tasks, out_dist, out_idx, out_keys, ncand, status, ws, window=None):
+        """The arguments of `nlsh_scan_topk_cells_phase` that do not change between batches of one shape, as plain ints:
         (everything before `queries`, everything between `q_stride`/`Q` and the events).  Callers that launch many
         batches (nlsh_amd/pipeline.py) build them once per buffer set; a call is then one ctypes transition."""
         a = lambda t: None if t is None else t.data_ptr()   # noqa: E731
         metric = (_capi.METRIC_L2_EPS_FOLDED if self.l2_form == "folded" else _capi.METRIC_L2_EPS) if self.metric == "l2" else _capi.METRIC_COSINE
-        pre = (a(self.corpus_sorted), self.row_stride, d, a(self.gid), a(self.uniq_keys), a(self.offsets), a(self.bucket_order),
-               self.n_buckets, a(self.inv_norm))
+        if window is None:
+            window = self.choose_window(Q, keys.shape[1], algo)
+        if window and algo == _capi.SCAN_BUCKET_TILED:
+            cell_of, cell_offsets, cell_order, nc = self.cells(window)
+            sched = (a(cell_order), self.n_buckets, a(cell_of), a(cell_offsets), nc)
+        else:
+            sched = (a(self.bucket_order), self.n_buckets, None, None, 0)
+        pre = (a(self.corpus_sorted), self.row_stride, d, a(self.gid), a(self.uniq_keys), a(self.offsets), *sched, a(self.inv_norm))
         post = (Q, a(keys), a(nkeys), keys.shape[1], k, metric, algo, self.seg_rows or 512, a(out_dist), a(out_idx), a(out_keys),
                 a(ncand), a(status), a(ws), ws.numel(), max_tasks)
         return pre, post
 
-    def _scan_launch(self, q, keys, nkeys, k, algo, max_tasks, out_dist, out_idx, out_keys, ncand, status, ws, phases, events=None):
-        """One `nlsh_scan_topk_phase` call on the current stream with caller-owned buffers (any subset of the phases)."""
+    def _scan_launch(self, q, keys, nkeys, k, algo, max_tasks, out_dist, out_idx, out_keys, ncand, status, ws, phases, events=None,
+                     window=None):
+        """One `nlsh_scan_topk_cells_phase` call on the current stream with caller-owned buffers (any subset of the phases)."""
         Q, d = q.shape
-        pre, post = self._scan_args(Q, d, keys, nkeys, k, algo, max_tasks, out_dist, out_idx, out_keys, ncand, status, ws)
-        _capi.check(_capi.lib().nlsh_scan_topk_phase(
+        pre, post = self._scan_args(Q, d, keys, nkeys, k, algo, max_tasks, out_dist, out_idx, out_keys, ncand, status, ws, window)
+        _capi.check(_capi.lib().nlsh_scan_topk_cells_phase(
             *pre, q.data_ptr(), q.stride(0) if Q else d, *post,
             events[0].cuda_event if events else None, events[1].cuda_event if events else None, _stream(q.device), phases))
 

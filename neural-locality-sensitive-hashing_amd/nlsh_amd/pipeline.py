@@ -57,7 +57,7 @@ class QueryPipeline:
         indexer.query_tensors(q, k=k, hash_times=hash_times, seed=0, check=True)     # sizes indexer._max_tasks
         torch.cuda.synchronize(dev)
         self.algo = indexer.last_algo
-        self.max_tasks = indexer._max_tasks[(self.algo, self.Q, self.P)]
+        self.max_tasks = indexer._max_tasks[indexer._last_tkey]
         ws_bytes = _capi.lib().nlsh_scan_workspace(self.Q, self.P, k, self.max_tasks, indexer.n_buckets, self.d)
         # the front and tail stages are small workgroups that must slip in beside the scan: their queues get the
         # higher priority
@@ -124,16 +124,16 @@ class QueryPipeline:
             seed = ix._hashing.next_seed()
         rc = L.nlsh_encode_hash(qp, self.Q, qs, *s.enc_pre, self._n_multi, seed, 0, *s.enc_post, front.cuda_stream)
         if rc == 0:
-            rc = L.nlsh_scan_topk_phase(*s.scan_pre, qp, qs, *s.scan_post, None, None, front.cuda_stream, _capi.PHASE_PLAN)
+            rc = L.nlsh_scan_topk_cells_phase(*s.scan_pre, qp, qs, *s.scan_post, None, None, front.cuda_stream, _capi.PHASE_PLAN)
         s.planned.record(front)
         mid.wait_event(s.planned)
         if rc == 0:
-            rc = L.nlsh_scan_topk_phase(*s.scan_pre, qp, qs, *s.scan_post, events[0].cuda_event if events else None,
+            rc = L.nlsh_scan_topk_cells_phase(*s.scan_pre, qp, qs, *s.scan_post, events[0].cuda_event if events else None,
                                         events[1].cuda_event if events else None, mid.cuda_stream, _capi.PHASE_SCAN)
         s.scanned.record(mid)
         tail.wait_event(s.scanned)
         if rc == 0:
-            rc = L.nlsh_scan_topk_phase(*s.scan_pre, qp, qs, *s.scan_post, None, None, tail.cuda_stream, _capi.PHASE_MERGE)
+            rc = L.nlsh_scan_topk_cells_phase(*s.scan_pre, qp, qs, *s.scan_post, None, None, tail.cuda_stream, _capi.PHASE_MERGE)
         _capi.check(rc)
         out = (s.out_dist, s.out_idx, s.ncand, s.out_keys)
         if self.exchange is not None:

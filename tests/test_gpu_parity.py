@@ -318,15 +318,15 @@ def test_task_table_overflow_is_detected_and_retried():
     hashing = make_hashing(d, (64,), H, Ws, bs)
     indexer = Indexer(hashing, dev(corpus), SIFT.distance, seg_rows=64)
     for algo in (0, 1, 2):
-        indexer._max_tasks[(algo, 80, 1)] = 5                       # far too small: must grow, not truncate
+        indexer._max_tasks[indexer._tkey(algo, 80, 1)] = 5                       # far too small: must grow, not truncate
     ids, nc = indexer.query(dev(queries), k=10, hash_times=1)
-    assert indexer._max_tasks[(indexer.last_algo, 80, 1)] > 5
+    assert indexer._max_tasks[indexer._tkey(indexer.last_algo, 80, 1)] > 5
     # the device-resident form detects it too (check=True) and a batch of another shape gets its own table
-    indexer._max_tasks[(indexer.last_algo, 80, 1)] = 5
+    indexer._max_tasks[indexer._tkey(indexer.last_algo, 80, 1)] = 5
     _, i2, n2, _ = indexer.query_tensors(dev(queries), k=10, hash_times=1)
-    assert n2.cpu().tolist() == nc and indexer._max_tasks[(indexer.last_algo, 80, 1)] > 5
+    assert n2.cpu().tolist() == nc and indexer._max_tasks[indexer._tkey(indexer.last_algo, 80, 1)] > 5
     ids40, nc40 = indexer.query(dev(queries[:40]), k=10, hash_times=1)
-    assert ids40 == ids[:40] and nc40 == nc[:40] and (indexer.last_algo, 40, 1) in indexer._max_tasks
+    assert ids40 == ids[:40] and nc40 == nc[:40] and indexer._tkey(indexer.last_algo, 40, 1) in indexer._max_tasks
     ox = oracle.OracleIndexer(Ws, bs, corpus)
     oids, onc = ox.query(queries, k=10, hash_times=1)
     assert nc == onc

@@ -43,18 +43,22 @@ def _build(d, metric, seed):
     return corpus, queries, corpus_keys, key_lists, buckets
 
 
-def _task_table(indexer, Qn, P, k, d):
-    """(nq, nrows) of every task the last tiled scan laid out, read from the workspace through the diagnostic layout call."""
+def _task_table(indexer, Qn, P, k, d, full=False):
+    """(nq, nrows) of every task the last tiled scan laid out, read from the workspace through the diagnostic layout call;
+    full=True: the whole table [tasks, 4] plus the tasks' query ids and packed row ranges, each [tasks, 16]."""
     L = _capi.lib()
-    tkey = indexer._last_tkey
-    max_tasks = indexer._max_tasks[tkey]
-    off_task, off_q = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    max_tasks = indexer._last_max_tasks                              # the table the LAST launch ran with (it may be trimmed afterwards)
+    off_task, off_q, off_r = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
     _capi.check(L.nlsh_scan_workspace_layout(Qn, P, k, max_tasks, indexer.n_buckets, d, _capi.SCAN_BUCKET_TILED,
-                                             ctypes.byref(off_task), ctypes.byref(off_q)))
+                                             ctypes.byref(off_task), ctypes.byref(off_q), ctypes.byref(off_r)))
     ws = next(w for (stream, bm), w in indexer._ws.items() if bm)
     n_tasks = int(indexer.last_status.cpu()[0])
     tab = ws[off_task.value:off_task.value + 16 * n_tasks].view(torch.int32).view(-1, 4).cpu().numpy()
-    return tab[:, 1], tab[:, 3]
+    if not full:
+        return tab[:, 1], tab[:, 3]
+    tq = ws[off_q.value:off_q.value + 64 * n_tasks].view(torch.int32).view(-1, 16).cpu().numpy()
+    tr = ws[off_r.value:off_r.value + 64 * n_tasks].view(torch.int32).view(-1, 16).cpu().numpy()
+    return tab, tq, tr
 
 
 @pytest.mark.parametrize("d", [128, 100, 96, 72])
@@ -67,7 +71,7 @@ def test_every_tiled_task_body_matches_the_oracle(metric, d):
     Ws, bs = synth.make_weights([d, 32, 16], seed=d)
     hashing = make_hashing(d, (32,), 16, Ws, bs, compat=False)     # the hash is not used: keys are injected on both sides
     indexer = Indexer(hashing, dev(corpus), SIFT.distance if metric == "l2" else Glove.distance, compat=False, algo="tiled",
-                      corpus_keys=dev(corpus_keys))
+                      corpus_keys=dev(corpus_keys), window_rows=0)   # one task list per bucket: the shapes below are per bucket
     res, nc, dist, idx = indexer.query_with_keys(dev(queries), key_lists, k=k)
     assert indexer.last_algo == _capi.SCAN_BUCKET_TILED
 
@@ -210,3 +214,113 @@ def test_folded_l2_form_is_an_opt_in_within_the_stated_tolerance(d):
     other = Indexer(hashing, dev(corpus), SIFT.distance, compat=False, algo="query", corpus_keys=dev(corpus_keys), l2_form="folded")
     r2 = other.query_with_keys(dev(queries), key_lists, k=k)
     assert r2[1] == r0[1] and np.all(np.abs(r2[2].cpu().numpy()[fin] - d0[fin]) <= 2e-5 * np.maximum(1.0, np.abs(d0[fin])))
+
+
+def _greedy_cells(offsets, W, span=1024):
+    """Host restatement of nlsh_build_cells' packing rule (include/nlsh_hip.h): CSR order, restarted every `span` buckets; a
+    bucket of more than W rows is its own cell, smaller ones join the open cell while its rows stay <= W."""
+    nb = len(offsets) - 1
+    starts = np.zeros(nb, np.int32)
+    cur = -1
+    for b in range(nb):
+        if b % span == 0:
+            cur = -1
+        s_, e_ = int(offsets[b]), int(offsets[b + 1])
+        if e_ - s_ > W:
+            starts[b], cur = 1, -1
+        elif cur < 0 or e_ - cur > W:
+            starts[b], cur = 1, s_
+    cell_of = np.cumsum(starts) - 1
+    cell_offsets = np.append(offsets[:-1][starts == 1], offsets[-1])
+    return cell_of.astype(np.int32), cell_offsets.astype(np.int32)
+
+
+@pytest.mark.parametrize("window", [64, 128, 256])
+def test_build_cells_is_the_greedy_packing(window):
+    from nlsh_amd.data import SIFT
+    from nlsh_amd.indexer import Indexer
+    rng = np.random.default_rng(window)
+    # 5,000 buckets (several 1024-bucket spans): mostly tiny, some around the window size, a few far larger
+    sizes = np.concatenate([rng.integers(1, 20, 3000), rng.integers(1, 2 * window, 1500), rng.integers(257, 3000, 500)])
+    rng.shuffle(sizes)
+    keys = np.repeat(np.arange(len(sizes), dtype=np.int32) * 2 - 5000, sizes)
+    d = 8
+    corpus = rng.standard_normal((len(keys), d)).astype(np.float32)
+    Ws, bs = synth.make_weights([d, 8, 16], seed=1)
+    ix = Indexer(make_hashing(d, (8,), 16, Ws, bs, compat=False), dev(corpus), SIFT.distance, compat=False, corpus_keys=dev(keys))
+    cell_of, cell_offsets, cell_order, nc = ix.cells(window)
+    offs = ix.offsets.cpu().numpy()
+    want_of, want_offs = _greedy_cells(offs, window)
+    assert nc == len(want_offs) - 1 and nc < ix.n_buckets
+    assert np.array_equal(cell_of.cpu().numpy(), want_of)
+    assert np.array_equal(cell_offsets.cpu().numpy(), want_offs)
+    rows = np.diff(want_offs)
+    order = cell_order.cpu().numpy()
+    assert sorted(order.tolist()) == list(range(nc))                 # a permutation of the cells ...
+    assert np.all(np.diff(rows[order]) <= 0)                         # ... by descending rows
+    multi = np.bincount(want_of) > 1
+    assert multi.any() and rows[multi].max() <= window               # shared windows exist and none exceeds the window
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine"])
+@pytest.mark.parametrize("d", [128, 100])
+def test_shared_windows_change_no_result_bit(metric, d):
+    """Small-bucket packing (nlsh_build_cells): consecutive small buckets share a row window and its tasks, each (task, query) with
+    the row range of its own bucket.  Every distance is the same fmaf chain over the same row, so ids, distances and counts must be
+    bit-identical to the one-task-list-per-bucket layout for every window size -- L2 and cosine alike -- while the task count drops;
+    the ranges the PLAN phase wrote are checked against the CSR."""
+    from nlsh_amd.data import Glove, SIFT
+    from nlsh_amd.indexer import Indexer
+    k = 10
+    rng = np.random.default_rng(7 * d)
+    # tiny buckets in runs (shared windows), mid-size ones, and big ones that break the runs; every bucket probed by 0..20 queries
+    sizes = np.concatenate([rng.integers(1, 12, 400), rng.integers(12, 130, 120), rng.integers(130, 257, 30), rng.integers(257, 700, 12)])
+    rng.shuffle(sizes)
+    N = int(sizes.sum())
+    gen = synth.sift_like if metric == "l2" else synth.glove_like
+    corpus, queries = gen(N, d, seed=d), gen(Q, d, seed=d + 1)
+    corpus[N // 2:N // 2 + 40] = corpus[:40]                        # exact distance ties across buckets and windows
+    bkeys = np.arange(len(sizes), dtype=np.int32) * 5 - 1300
+    corpus_keys = np.repeat(bkeys, sizes)                           # rows in bucket order: windows are runs of the corpus itself
+    key_lists = [[] for _ in range(Q)]
+    for b in range(len(sizes)):
+        for q in rng.choice(Q, size=int(rng.integers(0, 21)) if b % 3 else int(rng.integers(0, 3)), replace=False):
+            if len(key_lists[q]) < _capi.MAX_PROBES:
+                key_lists[q].append(int(bkeys[b]))
+    for q in range(Q):
+        rng.shuffle(key_lists[q])
+    Ws, bs = synth.make_weights([d, 32, 16], seed=d)
+    hashing = make_hashing(d, (32,), 16, Ws, bs, compat=False)
+    dist_fn = SIFT.distance if metric == "l2" else Glove.distance
+    P = max(len(ks) for ks in key_lists)
+    base = Indexer(hashing, dev(corpus), dist_fn, compat=False, algo="tiled", corpus_keys=dev(corpus_keys), window_rows=0)
+    r0 = base.query_with_keys(dev(queries), key_lists, k=k)
+    n0 = int(base.last_status.cpu()[0])
+    offs = base.offsets.cpu().numpy()
+    uniq = base.uniq_keys.cpu().numpy()
+    for window in (64, 128, 256):
+        ix = Indexer(hashing, dev(corpus), dist_fn, compat=False, algo="tiled", corpus_keys=dev(corpus_keys), window_rows=window)
+        r1 = ix.query_with_keys(dev(queries), key_lists, k=k)
+        assert ix.last_window == window
+        assert r1[0] == r0[0] and r1[1] == r0[1]
+        assert torch.equal(r1[3], r0[3]) and torch.equal(r1[2].view(torch.int32), r0[2].view(torch.int32))
+        tab, tq, tr = _task_table(ix, Q, P, k, d, full=True)
+        assert len(tab) < n0                                         # fewer, fuller tasks
+        cell_of, cell_offsets, _, nc = ix.cells(window)
+        coffs = cell_offsets.cpu().numpy()
+        shared = 0
+        for (pair0, nq, row0, nrows), qs_, rs_ in zip(tab.tolist(), tq.tolist(), tr.tolist()):
+            assert 1 <= nq <= 16 and 1 <= nrows <= 256
+            c = int(np.searchsorted(coffs, row0, side="right")) - 1
+            assert coffs[c] <= row0 < coffs[c + 1]
+            spans = set()
+            for slot in range(nq):
+                lo, hi = rs_[slot] & 0xFFFF, rs_[slot] >> 16
+                assert 0 <= lo < hi <= nrows
+                b = int(np.searchsorted(offs, row0 + lo, side="right")) - 1
+                # the range is exactly the part of ONE bucket that lies in this task's rows, and the query probes that bucket
+                assert max(offs[b], row0) == row0 + lo and min(offs[b + 1], row0 + nrows) == row0 + hi
+                assert int(uniq[b]) in key_lists[qs_[slot]]
+                spans.add((lo, hi))
+            shared += len(spans) > 1
+        assert shared > 0                                            # windows shared by queries of DIFFERENT buckets were exercised

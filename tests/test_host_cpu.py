@@ -22,7 +22,7 @@ def test_capi_library_exports_every_declared_symbol():
     lib = _capi.lib()
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} not exported"
-    assert lib.nlsh_abi_version() == 1
+    assert lib.nlsh_abi_version() == 2
     # pure host-side argument validation (no device needed): errors come back as codes + message
     dims = _capi.int_array([128, 256, 256, 16])
     assert lib.nlsh_encoder_packed_floats(3, dims) == 256 * 128 + 256 + 256 * 256 + 256 + 32 * 256 + 32

@@ -17,12 +17,26 @@ from nlsh_amd import _capi, io, synth  # noqa: E402
 from nlsh_amd.data import SIFT  # noqa: E402
 from nlsh_amd.indexer import Indexer  # noqa: E402
 
-N, d, Q = 1_000_000, 128, 10_000
-corpus_h, mean, std = synth.standardise(synth.sift_manifold(N, d, seed=synth.SEED_DATA))
-queries_h, _, _ = synth.standardise(synth.sift_manifold(Q, d, seed=synth.SEED_QUERY), mean, std)
-Ws, bs = io.load_hasher_weights(os.path.join(ROOT, "neural-locality-sensitive-hashing_amd", "checkpoints", "sift1m_manifold_h16.npz"))
-hashing = io.hashing_from_weights(Ws, bs, compat=True)
-indexer = Indexer(hashing, torch.from_numpy(corpus_h).cuda(), SIFT.distance, algo="tiled")
+import argparse  # noqa: E402
+from nlsh_amd.data import Glove  # noqa: E402
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="sift1m", choices=["sift1m", "clusters", "glove"])
+ap.add_argument("--window", type=int, default=None, help="row window of the small-bucket packing (default: the facade's choice)")
+args = ap.parse_args()
+Q = 10_000
+if args.workload == "glove":
+    N, d = 1_183_514, 100
+    corpus_h, queries_h = synth.glove_manifold(N, d, seed=synth.SEED_DATA), synth.glove_manifold(Q, d, seed=synth.SEED_QUERY)
+    ck, dist_fn, compat = "glove_manifold_h24.npz", Glove.distance, False
+else:
+    N, d = 1_000_000, 128
+    gen = synth.sift_manifold if args.workload == "sift1m" else synth.sift_like
+    corpus_h, mean, std = synth.standardise(gen(N, d, seed=synth.SEED_DATA))
+    queries_h, _, _ = synth.standardise(gen(Q, d, seed=synth.SEED_QUERY), mean, std)
+    ck, dist_fn, compat = ("sift1m_manifold_h16.npz" if args.workload == "sift1m" else "sift1m_clusters_h16.npz"), SIFT.distance, True
+Ws, bs = io.load_hasher_weights(os.path.join(ROOT, "neural-locality-sensitive-hashing_amd", "checkpoints", ck))
+hashing = io.hashing_from_weights(Ws, bs, compat=compat)
+indexer = Indexer(hashing, torch.from_numpy(corpus_h).cuda(), dist_fn, compat=compat, algo="tiled", window_rows=args.window)
 queries = torch.from_numpy(queries_h).cuda()
 for i in range(3):
     indexer.query_tensors(queries, k=10, hash_times=10, seed=7)
@@ -32,7 +46,7 @@ L = _capi.lib()
 buf = np.zeros((min(n_tasks, 1 << 16), 8), dtype=np.float32)
 rc = L.nlsh_debug_scan_trace(buf.ctypes.data_as(ctypes.c_void_p), int(buf.size))
 assert rc == 0, rc
-np.save(os.path.join(ROOT, 'gpurun_out', 'scan_trace.npy'), buf)
+np.save(os.path.join(ROOT, 'gpurun_out', f'scan_trace_{args.workload}_{args.window}.npy'), buf)
 buf = buf[buf[:, 0] > 0]
 start = buf[:, 7].astype(np.int64)
 nq_nrows = buf[:, 6].astype(np.int64)
