@@ -57,8 +57,8 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (155 TF measured)
 VALU_F32_PEAK_TFLOPS = 157.3  # same figure: 1024 SIMDs x 2.4 GHz x 64 lanes x 2 flop / 2 cycles per wave64 v_fma_f32
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_r03.json")
-KERNEL_SOURCES = ("scan_bucket.hip", "scan_common.h", "scan_topk.hip", "common.h")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_r04.json")
+KERNEL_SOURCES = ("scan_bucket.hip", "scan_common.h", "scan_topk.hip", "common.h", "build_csr.hip")   # build_csr.hip: the cell packing shapes the scan's tasks
 
 
 def kernel_source_hash():
@@ -98,6 +98,15 @@ def parse(argv=None):
                     help="device-resident region only.  on: three-stage pipeline over three HIP streams; off: every kernel of a "
                          "step back to back on one stream (each kernel alone on the chip); auto: on for N>1, off for N=1")
     ap.add_argument("--algo", default=None, choices=["query", "bucket", "tiled"], help="force a scan schedule (default: auto)")
+    ap.add_argument("--window", type=int, default=None, help="row window of the tiled schedule's small-bucket packing (default: the facade's choice, 64; 0 = one task list per bucket)")
+    ap.add_argument("--l2-form", default="exact", choices=["exact", "folded"],
+                    help="exact (default): sqrt(sum(((q - c) + 1e-6)^2)) in F.pairwise_distance's operation order, bit-identical to the oracle.  folded: the "
+                         "WHOLE line (value, roofline, recall) is measured with Indexer(l2_form='folded') = NLSH_METRIC_L2_EPS_FOLDED, "
+                         "sqrt(sum(((q + 1e-6) - c)^2)): inside BASELINE.json's 1e-4 tolerance, not the oracle's bits; config.l2_form says so")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "allgather"],
+                    help="N>1, bucket shards: how rows reach their bucket's owner at index build.  auto: one all_to_all_single with uneven splits "
+                         "(probed first, agreed by all ranks); allgather: all-gather + local selection (the fallback, selectable so that a first "
+                         "contact with a fabric that refuses uneven all-to-all does not cost the run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--random-init", action="store_true", help="ignore the learned-hash checkpoint")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of each baseline sample")
@@ -148,6 +157,8 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+    if args.exchange == "allgather":
+        os.environ["NLSH_SHARD_EXCHANGE"] = "allgather"
     if os.environ.get("NLSH_BENCH_SAME_DEVICE"):  # rehearsal of the N>1 path on a one-GPU box (gloo, all ranks on cuda:0)
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -212,16 +223,17 @@ def main():
     sharded = None
     if world > 1:   # build-time exchange (all-gather of keys + all-to-all of rows for --shard buckets) is inside build_s
         sharded = ShardedIndexer(hashing, shard, distance, id_base=lo, shard=args.shard, compat=H <= 16,
-                                 seg_rows=args.seg_rows, algo=args.algo)
+                                 seg_rows=args.seg_rows, algo=args.algo, l2_form=args.l2_form, window_rows=args.window)
         indexer = sharded.local
     else:
-        indexer = Indexer(hashing, shard, distance, compat=H <= 16, seg_rows=args.seg_rows, algo=args.algo)
+        indexer = Indexer(hashing, shard, distance, compat=H <= 16, seg_rows=args.seg_rows, algo=args.algo, l2_form=args.l2_form,
+                          window_rows=args.window)
     torch.cuda.synchronize()
     build_s = time.time() - t0
     rebuild_s = None
     if world == 1:      # the build that recurs (the reference rebuilds every 300 training steps, main.py:402): allocator warm
         t0 = time.time()
-        Indexer(hashing, shard, distance, compat=H <= 16, seg_rows=args.seg_rows, algo=args.algo)
+        Indexer(hashing, shard, distance, compat=H <= 16, seg_rows=args.seg_rows, algo=args.algo, l2_form=args.l2_form, window_rows=args.window)
         torch.cuda.synchronize()
         rebuild_s = time.time() - t0
     if args.query_chunks is not None:
@@ -244,38 +256,40 @@ def main():
 
     # ------------------------------------------------------------------ region A: the reference's protocol (headline)
     # `value`: every call returns ALL Q result lists to the calling rank, at every N (the reference's deliverable,
-    # nlsh/trainers/base.py:93-96), with the facade's opt-in `Indexer.defer_result_release` ON (the previous call's dead lists are
-    # freed under the next call's scan); the same region with the facade's defaults is reported beside it
-    # (`protocol_qps_default`), and at N>1 the variant in which rank r only builds the lists of its Q/N slice (`own_slice_qps`).
-    def protocol_region(own, defer):
-        Indexer.defer_result_release = defer
+    # nlsh/trainers/base.py:93-96), with the facade's DEFAULTS -- what an unmodified `Trainer.fit` gets.  The same region with the
+    # facade's host-side opt-ins on (`Indexer.defer_result_release`, `Indexer.untracked_results`: INTEGRATION.md) is reported beside it
+    # as `protocol_qps_opt_in`, and at N>1 the variant in which rank r only builds the lists of its Q/N slice (`own_slice_qps`).
+    def protocol_region(own, opt_in):
+        saved = (Indexer.defer_result_release, Indexer.untracked_results)
+        Indexer.defer_result_release = Indexer.untracked_results = bool(opt_in)
+        try:
+            def query_lists(i):
+                if sharded is not None:   # same seed on every rank
+                    return sharded.query(qb[i % B], k=k, hash_times=P, seed=5000 + i, own_slice=own)
+                return indexer.query(qb[i % B], k=k, hash_times=P)
 
-        def query_lists(i):
-            if sharded is not None:   # same seed on every rank
-                return sharded.query(qb[i % B], k=k, hash_times=P, seed=5000 + i, own_slice=own)
-            return indexer.query(qb[i % B], k=k, hash_times=P)
+            held = None
+            for i in range(max(warmup, 1)):        # at least one: sizes the task table (may retry once); untimed
+                held = query_lists(-1 - i)         # held like the timed loop holds them: the previous call's lists die when the next arrive
+            fence()
+            calls = []
+            t0 = time.perf_counter()
+            for i in range(steps):
+                t1 = time.perf_counter()
+                held = query_lists(i)
+                calls.append(time.perf_counter() - t1)
+            fence()
+            el = max_over_ranks(time.perf_counter() - t0)
+            return el, calls, held
+        finally:
+            Indexer.defer_result_release, Indexer.untracked_results = saved
 
-        held = None
-        for i in range(max(warmup, 1)):        # at least one: sizes the task table (may retry once); untimed
-            held = query_lists(-1 - i)         # held like the timed loop holds them: the previous call's lists die when the next arrive
-        fence()
-        calls = []
-        t0 = time.perf_counter()
-        for i in range(steps):
-            t1 = time.perf_counter()
-            held = query_lists(i)
-            calls.append(time.perf_counter() - t1)
-        fence()
-        el = max_over_ranks(time.perf_counter() - t0)
-        Indexer.defer_result_release = False
-        return el, calls, held
-
-    elapsed, call_s, (ids_api, nc_api) = protocol_region(own=False, defer=True)
+    elapsed, call_s, (ids_api, nc_api) = protocol_region(own=False, opt_in=False)
     assert isinstance(ids_api, list) and len(ids_api) == Q and isinstance(nc_api, list)
-    elapsed_default, _, _ = protocol_region(own=False, defer=False)
+    elapsed_opt_in, _, _ = protocol_region(own=False, opt_in=True)
     elapsed_own = None
     if sharded is not None:
-        elapsed_own, _, (ids_own, _) = protocol_region(own=True, defer=True)
+        elapsed_own, _, (ids_own, _) = protocol_region(own=True, opt_in=False)
         q_lo, q_hi = shard_range(Q, rank, world)
         assert len(ids_own) == q_hi - q_lo
 
@@ -336,7 +350,7 @@ def main():
     # vector operations per element instead of three, one rounding per element away from the reference's order; never the default,
     # never `value` or `roofline`) -- reported beside the shipped bit-exact form
     folded = None
-    if world == 1 and pipe is None and metric == "l2":
+    if world == 1 and pipe is None and metric == "l2" and args.l2_form == "exact":
         ev_f = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         for a, b in ev_f:
             a.record(); b.record()
@@ -352,8 +366,15 @@ def main():
             el_f = time.perf_counter() - t0
             folded = {"scan_avg_ms": float(np.mean([a.elapsed_time(b) for a, b in ev_f])), "device_resident_ms_per_step": 1e3 * el_f / steps,
                       "device_resident_qps": Q * steps / el_f, "algo": int(indexer.last_algo)}
+            d_f, i_f, _, _ = indexer.query_tensors(qb[0], k=k, hash_times=P, seed=5000)
         finally:
             indexer.l2_form = "exact"
+        # how far apart the two forms are on this batch: id lists that differ at all, and the largest relative distance difference
+        # (tests/test_gpu_fullsize.py holds every difference to a k-th-distance tie within 1e-4 and recall@10 to equality)
+        d_e, i_e, _, _ = indexer.query_tensors(qb[0], k=k, hash_times=P, seed=5000)
+        both = (i_e >= 0) & (i_f >= 0)
+        folded["id_lists_differing"] = int((i_e != i_f).any(1).sum().item())
+        folded["max_rel_distance_diff"] = float(((d_e - d_f).abs() / d_e.abs().clamp(min=1.0))[both].max().item()) if bool(both.any()) else 0.0
 
     # N=1: the same K device-resident steps through the three-stage pipeline as well (what a serving loop would run; the
     # sequential region above is the one whose scan kernel is timed alone on the chip for the roofline)
@@ -375,14 +396,23 @@ def main():
         del alt
 
     # candidates per launch of the timed device steps (untimed recomputation with the same batches and probe seeds)
-    sum_c = []
+    sum_c, uniq_rows = [], []
     tables = dict(indexer._max_tasks)          # task tables as the timed steps saw them
+    bucket_rows = (indexer.offsets[1:] - indexer.offsets[:-1]).long() if indexer.n_buckets else None
     for i in range(steps):
         sum_c.append(int(indexer.query_tensors(qb[i % B], k=k, hash_times=P, seed=1000 + i)[2].long().sum().item()))
+        # rows of the buckets the batch probes at all, each counted ONCE: what a schedule that shares a fetched row between the
+        # queries probing its bucket has to read at least (the bucket-major schedules' algorithmic bytes)
+        if bucket_rows is not None:
+            kk, nn = indexer.hash_device(qb[i % B], hash_times=P, seed=1000 + i)
+            pos = torch.searchsorted(indexer.uniq_keys, kk.clamp(min=int(indexer.uniq_keys[0]), max=int(indexer.uniq_keys[-1]))).clamp(max=indexer.n_buckets - 1)
+            hit = (indexer.uniq_keys[pos] == kk) & (torch.arange(kk.shape[1], device=dev)[None, :] < nn[:, None])
+            uniq_rows.append(int(bucket_rows[torch.unique(pos[hit])].sum().item()))
         # every timed step (not only the last, whose status word was read above) fitted its task table
         needed, tkey = int(indexer.last_status.cpu()[0]), indexer._last_tkey
         assert tkey not in tables or needed <= tables[tkey], f"step {i}: {needed} tasks > table {tables[tkey]} inside the timed region"
     sum_c_local = float(np.mean(sum_c))
+    unique_bytes = 4.0 * d * float(np.mean(uniq_rows)) if uniq_rows else 0.0
     algo_bytes = 4.0 * d * sum_c_local
     flops_per_pair = 3.0 * d if metric == "l2" else 2.0 * d      # (q-c), +eps, fma per element | one fma
     algo_flops = flops_per_pair * sum_c_local
@@ -420,14 +450,13 @@ def main():
     traffic, valu_insts, traffic_src, clock_held = None, None, None, None
     try:
         tr = json.load(open(TRAFFIC_FILE))
-        w = tr["workload"]
-        if (w["N"], w["d"], w["Q"], w["H"], w["hash_times"]) == (N, d, Q, H, P) and world == 1 and "learned" in hash_desc \
-                and args.workload == "sift1m" and args.data == "manifold" and tr.get("kernel_source_sha256") == kernel_source_hash():
-            traffic = tr["traffic_bytes_per_launch"].get(str(indexer.last_algo))
-            valu_insts = tr.get("valu_wave_instructions_per_launch", {}).get(str(indexer.last_algo))
-            clock_held = tr.get("clock_held_GHz", {}).get(str(indexer.last_algo))
-            traffic_src = "profiles/" + os.path.basename(TRAFFIC_FILE) + " (rocprofv3 --pmc on the profile box, same workload; not this run)"
-    except (OSError, KeyError, ValueError):
+        ent = tr["entries"].get(f"{args.workload}:{args.data}:{args.l2_form}")
+        if ent is not None and world == 1 and "learned" in hash_desc and tr.get("kernel_source_sha256") == kernel_source_hash():
+            w = ent["workload"]
+            if (w["N"], w["d"], w["Q"], w["H"], w["hash_times"], w["algo"], w["window_rows"]) == (N, d, Q, H, P, int(indexer.last_algo), int(indexer.last_window)):
+                traffic, valu_insts, clock_held = ent["traffic_bytes_per_launch"], ent.get("valu_wave_instructions_per_launch"), ent.get("clock_held_GHz")
+                traffic_src = "profiles/" + os.path.basename(TRAFFIC_FILE) + " (rocprofv3 --pmc on the profile box, same workload, schedule and kernel sources; not this run)"
+    except (OSError, KeyError, ValueError, TypeError):
         pass
 
     result = None
@@ -451,12 +480,23 @@ def main():
                   2: "bscan3_kernel (bucket-major, LDS-tiled)"}[algo] + " " + metric
         if algo == _capi.SCAN_QUERY_MAJOR:
             roof = {"bound": "hbm", "kernel": kernel, "achieved": algo_bytes / t_scan / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
+            roof["frac"] = roof["achieved"] / roof["peak"]
         else:
-            roof = {"bound": "valu", "kernel": kernel, "achieved": algo_flops / t_scan / 1e12, "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "note": "bucket-major schedules fetch a row once per query group: fp32 VALU issue binds, not HBM (traffic << algorithmic "
-                            "bytes); achieved = flops_per_pair*d-weighted sum C_q / kernel time; peak = fp32 vector peak (contract's 'mfma' "
-                            "slot does not apply: the distance math is VALU by design, north_star keeps MFMA for the encoder)"}
-        roof["frac"] = roof["achieved"] / roof["peak"]
+            # The bucket-major schedules fetch a corpus row once per query GROUP, so SURVEY 8(d)'s per-pair bytes (4 d sum C_q) are not what
+            # they move (that rate is `algorithmic_GBps`, above the HBM peak on the headline).  Two roofs can bind them, both priced on
+            # ALGORITHMIC quantities measured live: fp32 vector issue on the 3 d (L2) / 2 d (cosine) flops per (query, candidate) pair, and
+            # HBM on the bytes of the DISTINCT candidate rows of the batch (each has to be read at least once).  `bound` is the one with
+            # the larger fraction: the skewed headline is VALU-bound, the balanced hashes with tiny buckets stream the corpus once.
+            valu_frac = algo_flops / t_scan / 1e12 / VALU_F32_PEAK_TFLOPS
+            hbm_frac = unique_bytes / t_scan / 1e9 / HBM_PEAK_GBPS
+            if valu_frac >= hbm_frac:
+                roof = {"bound": "valu", "kernel": kernel, "achieved": algo_flops / t_scan / 1e12, "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": valu_frac}
+            else:
+                roof = {"bound": "hbm", "kernel": kernel, "achieved": unique_bytes / t_scan / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_frac}
+            roof.update({"valu_frac": valu_frac, "hbm_frac_of_distinct_candidate_rows": hbm_frac, "distinct_candidate_row_bytes_per_launch": unique_bytes,
+                         "note": "bucket-major schedules share a fetched row between the queries of a group: bound = the larger of (pair flops / fp32 vector "
+                                 "peak) and (bytes of the batch's distinct candidate rows / HBM peak), both algorithmic and measured live; the contract's "
+                                 "'mfma' slot does not apply (the distance math is VALU by design, north_star keeps MFMA for the encoder)"})
         roof.update({"traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": scan_avg_ms,
                      "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_GBps": algo_bytes / t_scan / 1e9,
                      "algorithmic_flops_per_launch": algo_flops, "sum_candidates_per_launch": sum_c_local, "tasks_per_launch": n_tasks})
@@ -478,10 +518,17 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "recall_at_10": recall,
             "value_protocol": "Indexer.query(batch, k, hash_times) -> Python lists of ALL Q queries on the calling rank, K synchronous calls "
-                              "(nlsh/trainers/base.py:93-96); Indexer.defer_result_release=True (opt-in: the previous call's dead lists are freed under the "
-                              "next call's scan; INTEGRATION.md; protocol_qps_default is the same region with the facade's defaults)" + ("" if world == 1 else f"; sharded x{world}: every rank scans all queries over its shard, one "
-                                                    "all-gather + merge, every rank builds all Q lists"),
-            "protocol_qps_default": Q * steps / elapsed_default,
+                              "(nlsh/trainers/base.py:93-96), the facade's DEFAULT settings: what an unmodified Trainer.fit gets.  protocol_qps_opt_in is the same "
+                              "region with Indexer.defer_result_release = Indexer.untracked_results = True (host-side opt-ins, INTEGRATION.md)" +
+                              ("" if world == 1 else f"; sharded x{world}: every rank scans all queries over its shard, one all-gather + merge, every rank builds all Q "
+                               "lists -- the call is host-bound (Python list construction, ~0.9 ms per 10^4 queries at N=1), so `value` is ~flat in N BY CONSTRUCTION; "
+                               "the figure that scales is named by scaling_value_key"),
+            "protocol_qps_opt_in": Q * steps / elapsed_opt_in,
+            # the field of THIS line a scaling study should read: device-resident steps (results left in HBM, incl. the all-gather + merge at N>1);
+            # predicted ceiling from the one-GPU emulation of the per-rank local step (profiles/r03_shard_step_profile.jsonl: 0.360 / 0.224 / 0.166 /
+            # 0.140 ms at 1 / 2 / 4 / 8 shards -> at most 2.6x at N=8 before the exchange: encode + plan + merge are replicated on every rank)
+            "scaling_value_key": "device_resident_qps",
+            "scaling_ceiling_note": "per-rank local step emulated on one GPU: x1.6 / x2.2 / x2.6 at N = 2 / 4 / 8 before the all-gather (replicated per-batch kernels)",
             "own_slice_qps": None if elapsed_own is None else Q * steps / elapsed_own,
             "protocol_median_qps": Q / float(np.median(call_s)),
             "protocol_call_ms": [round(1e3 * c, 3) for c in call_s],
@@ -491,7 +538,7 @@ def main():
             "test_metrics": {"test/n_indexes": stats["n_indexes"], "test/std_index_rows": stats["std_index_rows"], "test/recall": recall,
                              "test/query_size": mean_c, "test/qps": Q * steps / elapsed},
             "config": {"workload": f"{wl['cfg']}, N={N} d={d} Q={Q} H={H} k={k} hash_times={P}, {B} query batches in rotation",
-                       "hash": hash_desc,
+                       "hash": hash_desc, "l2_form": args.l2_form if metric == "l2" else None, "window_rows": int(indexer.last_window),
                        "parallelism": (f"corpus {args.shard} sharded x{world} ({indexer._candidate_vectors_gpu.shape[0]} rows on rank 0), "
                                        f"all-gather of per-shard top-k + merge: {float(np.mean([a.elapsed_time(b) for a, b in ev_x])):.4f} ms/step"
                                        ) if world > 1 else "single GPU",
@@ -507,7 +554,9 @@ def main():
                         "bit-identical to the oracle, NOT what value / roofline above measure",
                 "avg_launch_ms": folded["scan_avg_ms"], "achieved": algo_flops / (folded["scan_avg_ms"] * 1e-3) / 1e12, "unit": "TFLOP/s",
                 "frac_of_valu_peak_on_the_same_algorithmic_flops": algo_flops / (folded["scan_avg_ms"] * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS,
-                "device_resident_ms_per_step": folded["device_resident_ms_per_step"], "device_resident_qps": folded["device_resident_qps"]}
+                "device_resident_ms_per_step": folded["device_resident_ms_per_step"], "device_resident_qps": folded["device_resident_qps"],
+                "id_lists_differing_from_exact": folded["id_lists_differing"], "of_queries": Q, "max_rel_distance_diff_vs_exact": folded["max_rel_distance_diff"],
+                "full_line": "python bench.py --l2-form folded prints the complete line (value, roofline, recall) measured on this form"}
         if enc is not None:
             result["encoder"] = enc
         if world == 1 and not args.no_cpu_baseline:

@@ -5,22 +5,23 @@
  * Plain CPython C API, no GPU code; optional: the facade falls back to `ndarray.tolist()` when the module is not built.
  * Same result, element for element (tests/test_host_cpu.py).
  *
- * The inner lists are handed out UNTRACKED by the cyclic garbage collector (PyObject_GC_UnTrack): a list of ints cannot be part of a
- * reference cycle, and CPython itself untracks tuples and dicts of atomic objects for the same reason.  10^4 tracked young lists per call
- * are what made the collector's next generation-0 pass cost 0.26 ms; untracked, they are invisible to it, and nothing
- * about the application's collector is touched (what Indexer.promote_results did with gc.freeze()).  They are ordinary lists in every other
- * respect (reference counting frees them as usual; list_dealloc untracks unconditionally).  The one thing a caller must not expect: a
- * reference CYCLE built through one of these lists later (row.append(row)) would not be found by the collector. */
+ * OPT-IN (fourth argument, default 0; `Indexer.untracked_results`): the inner lists are handed out UNTRACKED by the cyclic garbage
+ * collector (PyObject_GC_UnTrack).  A list of ints cannot be part of a reference cycle, and CPython itself untracks tuples and dicts of
+ * atomic objects for the same reason; 10^4 tracked young lists per call are what makes the collector's next generation-0 pass cost
+ * 0.26 ms, and untracked they are invisible to it.  But CPython never untracks LISTS: a caller that later builds a
+ * reference cycle through such a row (row.append(obj_that_references_row)) would leak it, so by default the rows are ordinary tracked
+ * lists, exactly what `.tolist()` returns in the reference (nlsh/indexer.py:91); r03 had this on whenever the helper was built. */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <stdint.h>
 
-/* rows_to_lists(buffer of int32 [Q, k] C-contiguous, Q, k) -> [[int] * k] * Q */
+/* rows_to_lists(buffer of int32 [Q, k] C-contiguous, Q, k, untrack=0) -> [[int] * k] * Q */
 static PyObject *rows_to_lists(PyObject *self, PyObject *args) {
     Py_buffer view;
     Py_ssize_t Q, k;
+    int untrack = 0;
     (void)self;
-    if (!PyArg_ParseTuple(args, "y*nn", &view, &Q, &k)) return NULL;
+    if (!PyArg_ParseTuple(args, "y*nn|p", &view, &Q, &k, &untrack)) return NULL;
     if (Q < 0 || k < 0 || view.len < Q * k * 4) {
         PyBuffer_Release(&view);
         PyErr_SetString(PyExc_ValueError, "rows_to_lists: buffer smaller than Q * k int32");
@@ -38,7 +39,7 @@ static PyObject *rows_to_lists(PyObject *self, PyObject *args) {
             if (!v) { Py_DECREF(outer); PyBuffer_Release(&view); return NULL; }
             PyList_SET_ITEM(row, j, v);
         }
-        PyObject_GC_UnTrack(row);
+        if (untrack) PyObject_GC_UnTrack(row);
     }
     PyBuffer_Release(&view);
     return outer;

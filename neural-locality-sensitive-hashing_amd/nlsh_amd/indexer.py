@@ -27,18 +27,20 @@ HASH_BATCH = 4096  # nlsh/indexer.py:40 default batch_size
 def _load_fastlists():
     """csrc/fastlists.c (built by the Makefile next to the HIP library): the result lists in one tight C loop.  Host-side and
     optional -- `ndarray.tolist()` builds the identical lists -- unlike the HIP library, which has no substitute."""
-    import glob
+    import importlib.machinery
     import importlib.util
     import os
-    for path in glob.glob(os.path.join(os.path.dirname(_capi.LIB_PATH), "_nlsh_fastlists*.so")):
+    # only a build for THIS interpreter's ABI (the Makefile names the file with `python3-config --extension-suffix`)
+    path = os.path.join(os.path.dirname(_capi.LIB_PATH), "_nlsh_fastlists" + importlib.machinery.EXTENSION_SUFFIXES[0])
+    if not os.path.exists(path):
+        return None
+    try:
         spec = importlib.util.spec_from_file_location("_nlsh_fastlists", path)
-        try:
-            mod = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(mod)
-            return mod.rows_to_lists
-        except ImportError:
-            continue
-    return None
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod.rows_to_lists
+    except (ImportError, OSError):
+        return None
 
 
 _rows_to_lists = _load_fastlists()
@@ -163,7 +165,7 @@ class Indexer:
                 raise ValueError("corpus_keys must be int32 [N] on the corpus device")
             keys = keys.contiguous()
         else:
-            keys, _ = self._hashing.hash_device(corpus, n=1)       # indexer.py:36-38: hash_times=1
+            keys, _ = self.hash_device(corpus, hash_times=1)       # indexer.py:36-38: hash(candidates, hash_times=1), in 4096-row batches when the module's mode makes batches matter
         self.corpus_keys = keys.view(-1)
         self.perm, self.uniq_keys, self.offsets = build_csr_device(self.corpus_keys)
         self.n_buckets = int(self.uniq_keys.shape[0])
@@ -218,6 +220,27 @@ class Indexer:
         return (n // batch_size) * batch_size if self.compat else n
 
     def hash_device(self, query_vectors, batch_size=HASH_BATCH, hash_times=1, seed=None, out=None):
+        needs_train = getattr(self._hashing, "_needs_train_forward", None)
+        if needs_train is not None and needs_train() and query_vectors.shape[0] > batch_size:
+            # BatchNorm encoder in TRAIN mode: the reference feeds the module `batch_size`-row batches (nlsh/indexer.py:40-53), so the
+            # batch statistics -- and the running-statistics updates -- are per batch, the trailing partial batch on its own
+            # statistics with n = 1 (F6).  One forward over all rows would use other statistics and hold every activation at once.
+            n, parts = query_vectors.shape[0], []
+            full = (n // batch_size) * batch_size
+            for lo in range(0, full, batch_size):
+                parts.append(self._hashing.hash_device(query_vectors[lo:lo + batch_size], n=hash_times, seed=seed))
+            if full < n:
+                tail_n = 1 if self.compat else hash_times
+                tk, tn = self._hashing.hash_device(query_vectors[full:], n=tail_n, seed=seed)
+                if tk.shape[1] < hash_times:
+                    tk = torch.nn.functional.pad(tk, (0, hash_times - tk.shape[1]))
+                parts.append((tk, tn))
+            keys, nkeys = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+            if out is not None:
+                out[0].copy_(keys)
+                out[1].copy_(nkeys)
+                keys, nkeys = out
+            return keys, nkeys
         return self._hashing.hash_device(query_vectors, n=hash_times,
                                          n_multi_rows=self._n_multi_rows(query_vectors.shape[0], batch_size), seed=seed, out=out)
 
@@ -563,6 +586,11 @@ class Indexer:
     # same reason as `promote_results`: a library call should not change object lifetimes unasked.  bench.py turns both on for its
     # headline region, says so, and reports the region with both off beside it.
     defer_result_release = False
+    # OPT-IN: hand the inner result lists out untracked by the cyclic collector (csrc/fastlists.c).  A row of ints cannot be part of a
+    # cycle and 10^4 tracked young lists per call make the collector's next young pass cost ~0.26 ms -- but CPython never untracks
+    # lists, and a caller that later stores something that references the row INTO the row would leak that cycle.  Off by default
+    # like the two switches above (r03 untracked whenever the helper was built).
+    untracked_results = False
     _FULL_COLLECT_EVERY = 2048
     _promotions = 0
 
@@ -576,7 +604,7 @@ class Indexer:
         gc.disable()        # 10^4 fresh lists would trigger a dozen collections over the whole heap: a third of the conversion
         try:
             if _rows_to_lists is not None and idx_h.dtype == np.int32 and idx_h.ndim == 2 and idx_h.flags.c_contiguous:
-                out = _rows_to_lists(idx_h, idx_h.shape[0], idx_h.shape[1]), nc_h.tolist()
+                out = _rows_to_lists(idx_h, idx_h.shape[0], idx_h.shape[1], bool(cls.untracked_results)), nc_h.tolist()
             else:
                 out = idx_h.tolist(), nc_h.tolist()
             if promote:
@@ -610,7 +638,11 @@ class Indexer:
 
     def _keep(self, result):
         if self.defer_result_release:
-            self.__dict__.setdefault("_held", []).append(result)
+            held = self.__dict__.setdefault("_held", [])
+            held.append(result)
+            # never more than the newest two, whichever path produced them: the generic-metric and sliced (hash_times > 64) paths do
+            # not pass through `_release_held`, and without this the list grew by one full result set per call
+            del held[:-2]
         elif self.__dict__.get("_held"):
             self._held = []
         return result

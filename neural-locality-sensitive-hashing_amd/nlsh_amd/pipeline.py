@@ -107,6 +107,11 @@ class QueryPipeline:
         The hasher's weights are the ones present at THIS call."""
         if queries.shape != (self.Q, self.d) or queries.dtype != torch.float32 or queries.stride(1) != 1:
             raise ValueError("batch shape/dtype differs from the pipeline's sample batch")
+        if self.indexer._hashing._needs_train_forward():
+            # the pipeline launches the fused kernel on folded eval-mode weights; a BatchNorm encoder in train mode needs the module's
+            # own batch-statistics forward (hashings._run_train_mode), which `Indexer.query` / `hash_device` route to
+            raise _capi.NlshHipError(_capi.E_UNSUPPORTED, "pipelined batches need the hasher in eval mode (BatchNorm encoder in train "
+                                                          "mode: call hashing.train_mode(False), or use Indexer.query)")
         ix, L = self.indexer, self._lib
         s = self.slots[self.n_submitted % len(self.slots)]
         self.n_submitted += 1

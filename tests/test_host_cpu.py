@@ -277,11 +277,37 @@ def test_fastlists_builds_the_same_lists_as_ndarray_tolist():
         got = indexer._rows_to_lists(a, shape[0], shape[1])
         assert got == a.tolist() and all(type(v) is int for row in got for v in row)
         assert all(type(row) is list for row in got)
-        # the inner lists (ints only: no cycle possible) are handed out untracked by the cyclic GC, the outer list is an ordinary one
+        # by default every list is an ordinary, collector-tracked one (what `.tolist()` returns: nlsh/indexer.py:91) ...
         import gc
-        assert gc.is_tracked(got) and not any(gc.is_tracked(row) for row in got)
+        assert gc.is_tracked(got) and all(gc.is_tracked(row) for row in got)
+        # ... and only the opt-in hands the inner rows out untracked (ints only: no cycle possible unless the caller builds one later)
+        opt = indexer._rows_to_lists(a, shape[0], shape[1], True)
+        assert opt == got and gc.is_tracked(opt) and not any(gc.is_tracked(row) for row in opt)
     with pytest.raises(ValueError):
         indexer._rows_to_lists(np.zeros((4, 4), np.int32), 5, 4)
     idx, nc = np.arange(5120, dtype=np.int32).reshape(512, 10), np.full((512,), 12, dtype=np.int32)
     lists, counts = indexer.Indexer._plain_lists(idx, nc)
     assert lists == idx.tolist() and counts == nc.tolist()
+    assert indexer.Indexer.untracked_results is False and all(gc.is_tracked(row) for row in lists)   # the facade's default: tracked
+    indexer.Indexer.untracked_results = True
+    try:
+        assert not any(gc.is_tracked(row) for row in indexer.Indexer._plain_lists(idx, nc)[0])
+    finally:
+        indexer.Indexer.untracked_results = False
+
+
+def test_deferred_release_never_holds_more_than_two_results():
+    """`defer_result_release` keeps the newest results alive so that the older one is freed under the next call's device work; the
+    paths that do not pass through `_release_held` (generic metric, hash_times > 64) used to grow the list by one result set per call."""
+    from nlsh_amd.indexer import Indexer
+    ix = Indexer.__new__(Indexer)
+    Indexer.defer_result_release = True
+    try:
+        for i in range(50):
+            ix._keep(([[i]], [1]))
+            assert len(ix._held) <= 2
+        assert ix._held[-1] == ([[49]], [1])
+    finally:
+        Indexer.defer_result_release = False
+    ix._keep(([], []))
+    assert ix._held == []
