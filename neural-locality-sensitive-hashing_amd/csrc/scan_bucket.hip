@@ -1148,6 +1148,8 @@ __device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, lo
             }
 #endif
             if (NLSH_ABLATE != 3) {
+                // (r04: one-tile tasks selecting from ONE key per lane instead of TPS with three absent -- a quarter of the ballots per
+                // bisection step -- measured equal on all three workloads, profiles/r04_select_nk1_ab.txt; not kept)
                 const uint64_t bound = select_k_smallest<TPS>(key, a.k, lane, out);
                 if (bound != KEY_NONE && lane == 0) atomicMin(a.tauq + qid[jq], (unsigned long long)bound);
             } else if (lane < a.k) out[lane] = key[0];

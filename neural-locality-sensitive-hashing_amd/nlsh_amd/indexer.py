@@ -257,28 +257,24 @@ class Indexer:
         return self._e_sb
 
     def choose_algo(self, Q, P):
-        """Bucket-major pays when a corpus row is a candidate of several queries of the batch: expected (query, probe) pairs per row
-        `reuse` ~ Q * P * E[bucket size of a row] / N.  The LDS-tiled schedule fetches a row once per 16 queries and needs no
-        cross-lane reduction; it takes the call from reuse >= 6 on, provided the buckets fill at least one 64-row tile on average
-        (size-biased mean >= 64 rows).  Measured boundaries (r03, profiles/r03_bench_glove*.json): the GloVe-1.2M-shaped run --
-        104 k buckets, size-biased mean 82 rows, reuse 6.9 -- scans in 0.217 ms tiled against 0.234 ms query-major (sequential step
-        0.247 vs 0.268 ms; r02: 0.199 vs 0.215), so it sits on the tiled side; r01's kernels had it the other way round (0.41 vs
-        0.21 ms), which is where the old `e_sb >= 256 and reuse >= 8` rule came from.  Below that, big buckets with moderate sharing
-        go to the wave-level bucket-major schedule, everything else (balanced hashes with tiny buckets, small batches) to the
-        query-major stream.  The rule is deterministic in whole-corpus statistics, so every shard count picks the same arithmetic."""
+        """The LDS-tiled bucket-major schedule from 64 (query, probe) pairs per batch on, the query-major stream below that.
+
+        r04, with small buckets sharing 64-row windows (`choose_window`), tools/scan_bench.py --queries Q --algo ..., scan kernel /
+        whole device step in ms on one box (profiles/r04_algo_by_batch_size.txt):
+                            Q = 1          16           200          1000         2500         5000         10000
+            GloVe   tiled   .011 / .113   .013 / .082   .017 / .082  .038 / .101  .068 / .135  .095 / .168  .123 / .22
+                    query   .043 / .093   .044 / .104   .050 / .135  .057 / .143  .071 / .158  .114 / .203  .237 (r03)
+            SIFT1M  tiled   .014 / .074   .014 / .074   .020 / .074  .051 / .104  .075 / .131  .163 / .222  .24
+                    query   .031 / .067   .046 / .080   .054 / .092  .069 / .108  .146 / .189  .846 / .924  1.65 (r01)
+        (the SURVEY-generator SIFT1M index behaves like GloVe; the wave-level bucket-major schedule, algo="bucket", lost every cell of
+        this table by 2-4x and is only reachable by name).  r03's rule sent balanced hashes with tiny buckets and small batches to the
+        query-major stream because a task per (bucket, query group) cost ~9 us of latency per pair; windows removed that.  Only a
+        batch of a handful of queries still prefers the query-major schedule's shorter PLAN phase (one kernel instead of four).
+        The rule depends on the batch shape alone, so every shard count picks the same arithmetic (`schedule_stats` is kept for the
+        sharded builds' interface and no longer enters)."""
         if self.algo is not None:
             return {"query": _capi.SCAN_QUERY_MAJOR, "bucket": _capi.SCAN_BUCKET_MAJOR, "tiled": _capi.SCAN_BUCKET_TILED}[self.algo]
-        if self.schedule_stats is not None:
-            e_sb, n = float(self.schedule_stats[0]), max(float(self.schedule_stats[1]), 1.0)
-        else:
-            e_sb = self._size_biased_bucket()
-            n = max(float(self.bucket_sizes.sum()), 1.0)
-        reuse = Q * P * e_sb / n
-        if e_sb >= 64 and reuse >= 6.0:
-            return _capi.SCAN_BUCKET_TILED
-        if e_sb >= 128 and reuse >= 3.0:
-            return _capi.SCAN_BUCKET_MAJOR
-        return _capi.SCAN_QUERY_MAJOR
+        return _capi.SCAN_BUCKET_TILED if Q * P >= 64 else _capi.SCAN_QUERY_MAJOR
 
     def cells(self, window_rows):
         """(cell_of, cell_offsets, cell_order, n_cells) of this index for one window size: `nlsh_build_cells`, once per (index, size)."""

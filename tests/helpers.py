@@ -103,3 +103,27 @@ def assert_lists_differ_only_at_ties(ids_a, ids_b, query, corpus, metric, rtol=2
     da, db = d64(ids_a), d64(ids_b)
     assert np.all(np.abs(da - db) <= rtol * np.maximum(1.0, np.abs(db))), "id lists differ beyond a distance tie"
     return False
+
+
+def l2_forms_differ_only_at_ties(qg, cg, d_exact, i_exact, d_folded, i_folded, rtol=1e-4):
+    """Full-size comparison of the two L2 forms on the device (BASELINE.json: "L2 within 1e-4"): returns the number of queries whose id
+    lists differ at all, after asserting that (a) every returned distance of the folded form is within rtol * max(1, d) of the exact
+    form's at the same rank, (b) where the lists differ, the fp64 distances (nlsh/data.py:201's formula) of the two lists agree rank
+    by rank to the same tolerance -- i.e. the lists name different members of a tie at that tolerance, nothing else -- and (c) the
+    candidate sets were the same (same padding)."""
+    assert torch.equal(i_exact < 0, i_folded < 0)
+    ok = i_exact >= 0
+    assert bool(((d_exact - d_folded).abs() <= rtol * d_exact.abs().clamp(min=1.0))[ok].all()), "folded distance outside the tolerance"
+    diff = (i_exact != i_folded).any(1)
+    n_diff = int(diff.sum().item())
+    if n_diff:
+        rows = torch.nonzero(diff)[:, 0]
+        q64 = qg[rows].double()[:, None, :]
+
+        def d64(ids):
+            c = cg[ids[rows].clamp(min=0).long()].double()
+            return (((q64 - c) + 1e-6) ** 2).sum(-1).sqrt()
+        da, db = d64(i_exact), d64(i_folded)
+        m = ok[rows]
+        assert bool(((da - db).abs() <= rtol * da.clamp(min=1.0))[m].all()), "id lists differ beyond a distance tie at the stated tolerance"
+    return n_diff

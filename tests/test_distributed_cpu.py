@@ -77,8 +77,8 @@ def test_shard_range_partitions_rows():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_two_rank_gloo_merge_equals_single_shard(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_merge_equals_single_shard(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     got = np.load(tmp_path / "merged.npz")
     from nlsh_amd import synth
@@ -119,7 +119,7 @@ def _exchange_case():
     return keys, rows
 
 
-@pytest.mark.parametrize("world,mode", [(2, "alltoall"), (3, "alltoall"), (2, "allgather")])
+@pytest.mark.parametrize("world,mode", [(2, "alltoall"), (3, "alltoall"), (2, "allgather"), (8, "alltoall"), (8, "allgather")])
 def test_gloo_bucket_exchange_moves_every_bucket_whole(tmp_path, world, mode):
     mp.spawn(_exchange_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
     from nlsh_amd.distributed import assign_buckets, corpus_statistics

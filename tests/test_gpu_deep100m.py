@@ -98,6 +98,18 @@ def test_deep100m_full_size_one_gpu():
         assert np.array_equal(idx[:S].cpu().numpy(), oi_global)
         assert np.array_equal(dist[:S].cpu().numpy().view(np.uint32), od.view(np.uint32))   # bit-identical L2 distances
 
+        # ---- the opt-in folded L2 form on ALL 100 k queries: differences from the exact form are ties at the stated tolerance only
+        from helpers import l2_forms_differ_only_at_ties
+        ix.l2_form = "folded"
+        try:
+            d_f, i_f, n_f, _ = ix.scan_tensors(qg, keys, nkeys, k=k)
+        finally:
+            ix.l2_form = "exact"
+        assert torch.equal(n_f, nc)
+        n_diff = l2_forms_differ_only_at_ties(qg, cg, dist, idx, d_f, i_f)
+        assert n_diff <= Q // 100, n_diff
+        print(f"[l2 forms, Deep100M] id lists differing: {n_diff} of {Q}")
+
         # ---- hard keys of a corpus slice: oracle forward + full-width pack
         z = oracle.mlp_forward(cg[:4096].cpu().numpy(), Ws, bs)
         _, p01 = oracle.head_probs(z)

@@ -1,37 +1,57 @@
 # End-of-round measurement set (run on the GPU box from the repo root through gpurun; results under gpurun_out/final/, the ones
-# to be judged are copied to profiles/ afterwards).  Needs lib/libnlsh_hip_trace.so for the clock pass:
+# to be judged are copied to profiles/ afterwards).  Two calls (the Deep100M part needs the box to itself for a few minutes):
+#   bash tools/final_measure.sh main     # tests, bench lines, kernel statistics, counters of configs[1] (both generators, both L2 forms) and configs[2]
+#   bash tools/final_measure.sh deep     # configs[4] on one GPU: pipelined line, sequential line, counters of the sequential command
+# Needs lib/libnlsh_hip_trace.so for the clock pass:
 #   make -C neural-locality-sensitive-hashing_amd/csrc VARIANT=trace EXTRA="-DNLSH_SCAN_TRACE -DNLSH_SCAN_TRACE_CLOCK"
 set -e
 R=$PWD
 O=$R/gpurun_out/final
 mkdir -p $O
-python -m pytest tests -m gpu -q -x 2>&1 | tail -2 > $O/tests.txt
-python bench.py > $O/bench.json 2> $O/bench.err
-python bench.py --data clusters --no-cpu-baseline > $O/bench_clusters.json 2>/dev/null
-python bench.py --workload glove --no-cpu-baseline --pipeline on > $O/bench_glove.json 2>/dev/null
-python bench.py --workload glove --no-cpu-baseline --pipeline on --algo query > $O/bench_glove_query_major.json 2>/dev/null
-for w in 1 2 4 8; do python tools/shard_step_profile.py --world $w --rank 0 --steps 50; done 2>/dev/null > $O/shard_step_profile.jsonl
-if [ -f $R/neural-locality-sensitive-hashing_amd/lib/libnlsh_hip_trace.so ]; then
-  NLSH_HIP_LIB=$R/neural-locality-sensitive-hashing_amd/lib/libnlsh_hip_trace.so python tools/scan_clock.py > $O/scan_clock.txt 2>/dev/null || true
+PMC="FETCH_SIZE SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU"
+pmc_bench() {   # $1 = tag, rest = bench.py flags: counters of the bench command in their own pass (no tracing domains beside --pmc)
+  tag=$1; shift
+  rm -rf /tmp/pm_$tag
+  (cd /tmp && TMPDIR=/tmp rocprofv3 --pmc $PMC --output-format csv -d /tmp/pm_$tag -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 --query-chunks 1 "$@" > $O/pmc_${tag}_line.json 2> /tmp/pm_$tag.err)
+  python3 $R/tools/pmc_summary.py /tmp/pm_$tag > $O/pmc_$tag.json
+}
+if [ "${1:-main}" = "main" ]; then
+  python -m pytest tests -m gpu -q -x 2>&1 | tail -2 > $O/tests.txt
+  python bench.py > $O/bench.json 2> $O/bench.err
+  python bench.py --l2-form folded --no-cpu-baseline > $O/bench_folded.json 2>/dev/null
+  python bench.py --data clusters --no-cpu-baseline > $O/bench_clusters.json 2>/dev/null
+  python bench.py --workload glove --no-cpu-baseline > $O/bench_glove.json 2>/dev/null
+  python bench.py --workload glove --no-cpu-baseline --algo query > $O/bench_glove_query_major.json 2>/dev/null
+  for w in 1 2 4 8; do python tools/shard_step_profile.py --world $w --rank 0 --steps 50; done 2>/dev/null > $O/shard_step_profile.jsonl
+  CLK=""
+  if [ -f $R/neural-locality-sensitive-hashing_amd/lib/libnlsh_hip_trace.so ]; then
+    NLSH_HIP_LIB=$R/neural-locality-sensitive-hashing_amd/lib/libnlsh_hip_trace.so python tools/scan_clock.py > $O/scan_clock.txt 2>/dev/null || true
+    CLK=$(grep -oE 'clock median [0-9.]+' $O/scan_clock.txt | head -1 | awk '{print $3}')
+  fi
+  # per-kernel statistics of the bench command (one row range per query() call: every scan launch has the full-batch grid)
+  rm -rf /tmp/kt && (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --no-cpu-baseline --query-chunks 1 > $O/bench_under_rocprof.json 2> /tmp/kt.err)
+  cp $(find /tmp/kt -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
+  python3 $R/tools/kernel_trace_regions.py /tmp/kt > $O/kernel_trace_regions.txt
+  rm -rf /tmp/kts && (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --output-format csv -d /tmp/kts -- python3 $R/tools/step_timeline.py > /dev/null 2> /tmp/kts.err)
+  python3 $R/tools/step_timeline.py --parse /tmp/kts > $O/step_timeline.txt 2>/dev/null || true
+  for wl in glove clusters; do
+    flags="--workload glove"; [ $wl = clusters ] && flags="--data clusters"
+    rm -rf /tmp/kt_$wl && (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$wl -- python3 $R/bench.py --no-cpu-baseline --query-chunks 1 $flags > $O/bench_${wl}_under_rocprof.json 2> /tmp/kt_$wl.err)
+    cp $(find /tmp/kt_$wl -name '*kernel_stats.csv' | head -1) $O/${wl}_kernel_stats.csv
+  done
+  pmc_bench sift1m
+  pmc_bench sift1m_folded --l2-form folded
+  pmc_bench clusters --data clusters
+  pmc_bench glove --workload glove
+  python3 tools/make_traffic.py --entry $O/pmc_sift1m.json:$O/pmc_sift1m_line.json${CLK:+:$CLK} --entry $O/pmc_sift1m_folded.json:$O/pmc_sift1m_folded_line.json \
+      --entry $O/pmc_clusters.json:$O/pmc_clusters_line.json --entry $O/pmc_glove.json:$O/pmc_glove_line.json > $O/traffic.json
+  cat $O/tests.txt; cat $O/bench.json
+else
+  CK=$R/neural-locality-sensitive-hashing_amd/checkpoints/deep100m_manifold_h32.npz
+  python tools/scale_deep100m.py --load-hash $CK > $O/deep100m_pipelined.log 2>&1
+  rm -rf /tmp/pm_deep
+  (cd /tmp && TMPDIR=/tmp rocprofv3 --pmc $PMC --output-format csv -d /tmp/pm_deep -- python3 $R/tools/scale_deep100m.py --load-hash $CK --pipeline off --steps 2 --recall-queries 0 > /tmp/pm_deep.out 2> /tmp/pm_deep.err)
+  python3 tools/pmc_summary.py /tmp/pm_deep bscan > $O/pmc_deep100m.json
+  python tools/scale_deep100m.py --load-hash $CK --pipeline off --pmc-summary $O/pmc_deep100m.json > $O/deep100m_sequential.log 2>&1
+  tail -1 $O/deep100m_pipelined.log; tail -1 $O/deep100m_sequential.log
 fi
-cd /tmp && export TMPDIR=/tmp
-# per-kernel statistics of the bench command (one row range per query() call: every scan launch has the full-batch grid)
-rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --no-cpu-baseline --query-chunks 1 > $O/bench_under_rocprof.json 2> /tmp/kt.err
-cp $(find /tmp/kt -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
-python3 $R/tools/kernel_trace_regions.py /tmp/kt > $O/kernel_trace_regions.txt
-# counters of the same command (their own pass: no tracing domains beside --pmc)
-rm -rf /tmp/pm && rocprofv3 --pmc FETCH_SIZE SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/pm -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 --query-chunks 1 > /tmp/pm.out 2> /tmp/pm.err
-python3 $R/tools/pmc_summary.py /tmp/pm > $O/pmc.json
-# the cosine bodies of the tiled kernel: SIFT1M buckets scored by cosine (same tasks as the headline), statistics + counters
-rm -rf /tmp/ktc && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktc -- python3 $R/tools/scan_bench.py --metric cosine --no-check > $O/scan_bench_cosine.json 2> /tmp/ktc.err
-cp $(find /tmp/ktc -name '*kernel_stats.csv' | head -1) $O/cosine_kernel_stats.csv
-rm -rf /tmp/pmc && rocprofv3 --pmc FETCH_SIZE SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/pmc -- python3 $R/tools/scan_bench.py --metric cosine --no-check --iters 5 > /tmp/pmc.out 2> /tmp/pmc.err
-python3 $R/tools/pmc_summary.py /tmp/pmc bscan3 > $O/cosine_pmc.json
-# GloVe-shaped run through the tiled schedule: statistics
-rm -rf /tmp/ktg && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktg -- python3 $R/tools/scan_bench.py --workload glove --no-check > $O/scan_bench_glove_tiled.json 2> /tmp/ktg.err
-cp $(find /tmp/ktg -name '*kernel_stats.csv' | head -1) $O/glove_tiled_kernel_stats.csv
-# the opt-in folded L2 form: counters
-rm -rf /tmp/pmf && rocprofv3 --pmc FETCH_SIZE SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/pmf -- python3 $R/tools/scan_bench.py --l2-form folded --no-check --iters 5 > /tmp/pmf.out 2> /tmp/pmf.err
-python3 $R/tools/pmc_summary.py /tmp/pmf bscan3 > $O/folded_pmc.json
-cd $R
-cat $O/tests.txt; cat $O/bench.json

@@ -38,6 +38,7 @@ def one_case(rng, case_id):
     k = int(rng.choice([1, 3, 10, 10, 10, 37, 64]))
     P = int(rng.choice([1, 2, 6, 10, 10, 33, 64, 100]))
     algo = rng.choice(["query", "bucket", "tiled", None])
+    window = [None, 0, 64, 128, 256][int(rng.integers(0, 5))]         # row window of the tiled schedule's small-bucket packing (never changes a bit)
     hidden = tuple(int(v) for v in rng.choice([32, 64, 96, 320], size=int(rng.integers(1, 3))))
     gen = synth.sift_like if metric == "l2" else synth.glove_like
     corpus, queries = gen(N, d, seed=1000 + case_id), gen(Q, d, seed=2000 + case_id)
@@ -50,8 +51,9 @@ def one_case(rng, case_id):
     if rng.integers(0, 3) == 0:                                     # skewed hash: a few huge buckets
         Ws[-1][: H // 2] *= 0.05
     hashing = make_hashing(d, hidden, H, Ws, bs, compat=compat)
-    desc = dict(metric=metric, d=d, H=H, compat=compat, N=N, Q=Q, k=k, P=P, algo=algo, hidden=hidden)
-    indexer = Indexer(hashing, torch.from_numpy(corpus).cuda(), SIFT.distance if metric == "l2" else Glove.distance, compat=compat, algo=algo)
+    desc = dict(metric=metric, d=d, H=H, compat=compat, N=N, Q=Q, k=k, P=P, algo=algo, hidden=hidden, window=window)
+    indexer = Indexer(hashing, torch.from_numpy(corpus).cuda(), SIFT.distance if metric == "l2" else Glove.distance, compat=compat, algo=algo,
+                      window_rows=window)
     qd = torch.from_numpy(queries).cuda()
     keys, nkeys = indexer.hash_device(qd, hash_times=P, seed=case_id)
     dist, idx, nc, _ = indexer.scan_tensors(qd, keys, nkeys, k=k)
@@ -93,6 +95,8 @@ def one_case(rng, case_id):
             assert lists[q] == (indexer._rows_of_key(ks[-1]) if ks else []), (desc, q)
     exact = int((idx == oi).all(1).sum())
     assert exact >= 0.9 * Q - 2, (desc, exact)      # fp32 near-ties may resolve either way; the checks above bound them
+    if indexer.last_algo == 2 and metric == "l2" and P <= 64:   # the tiled schedule's L2 is the oracle's k-ascending fmaf chain: every bit, every window
+        assert exact == Q and np.array_equal(dist.view(np.uint32), od.view(np.uint32)), (desc, exact)
     return desc, exact / Q
 
 

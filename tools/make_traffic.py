@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
-"""profiles/traffic_rNN.json from a `tools/pmc_summary.py` summary of a `rocprofv3 --pmc` pass over bench.py: the per-launch HBM
-traffic and VALU / SALU instruction counts of the scan kernel that `bench.py` quotes as `roofline.traffic` /
-`valu_wave_instructions_per_launch`, TOGETHER WITH the sha256 of the kernel sources they were measured on
-(`bench.kernel_source_hash()`): bench.py reports the counters only while that hash still matches the tree.
+"""profiles/traffic_rNN.json from `rocprofv3 --pmc` passes over bench.py: per workload, the per-launch HBM traffic and VALU / SALU
+instruction counts of the scan kernel that `bench.py` quotes as `roofline.traffic` / `valu_wave_instructions_per_launch`, TOGETHER
+WITH the sha256 of the kernel sources they were measured on (`bench.kernel_source_hash()`): bench.py reports the counters only while
+that hash still matches the tree, and only for the entry whose workload shape, schedule and row window equal the run's.
 
-    python tools/make_traffic.py PMC_SUMMARY.json [--clock-held GHZ] [--prev profiles/traffic_r02.json] > profiles/traffic_r03.json
+    python tools/make_traffic.py --entry PMC_SUMMARY.json:BENCH_LINE.json[:CLOCK_GHZ] [--entry ...] > profiles/traffic_r04.json
 
-Bytes = FETCH_SIZE (KB) x 1024 x 2: MI355X_MICROARCH.md, HBM section -- FETCH_SIZE counts 64 B per 128-B request for 16-byte-per-lane
-streams (calibrated in r01 on gather_rows: 516 MB read -> 544 MB counted).  Schedules the pass did not run (query-major, wave-level
-bucket-major: kernels unchanged since r01) are carried over from --prev and labelled so."""
+PMC_SUMMARY.json = tools/pmc_summary.py over the pass; BENCH_LINE.json = the line bench.py printed IN that pass (its config.shape and
+config.traffic_key name the entry).  Bytes = FETCH_SIZE (KB) x 1024 x 2: MI355X_MICROARCH.md, HBM section -- FETCH_SIZE counts 64 B
+per 128-B request for 16-byte-per-lane streams (calibrated in r01 on gather_rows: 516 MB read -> 544 MB counted)."""
 import argparse
 import json
 import os
@@ -20,32 +20,29 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("pmc")
-    ap.add_argument("--clock-held", type=float, default=None)
-    ap.add_argument("--prev", default=os.path.join(ROOT, "profiles", "traffic_r02.json"))
-    ap.add_argument("--method", default="")
+    ap.add_argument("--entry", action="append", required=True)
+    ap.add_argument("--method", default="rocprofv3 --pmc FETCH_SIZE SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU -- "
+                                         "python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 --query-chunks 1 [workload flags] (tools/final_measure.sh); per-launch average "
+                                         "of the scan kernel (tools/pmc_summary.py); bytes = FETCH_SIZE(KB) * 1024 * 2")
     args = ap.parse_args()
     import bench
-    pmc = json.load(open(args.pmc))
-    prev = json.load(open(args.prev))
-    name = next(k for k in pmc if "bscan3_kernel<0" in k)
-    c = pmc[name]
-    out = {
-        "workload": prev["workload"],
-        "kernel_source_sha256": bench.kernel_source_hash(),
-        "kernel_sources": list(bench.KERNEL_SOURCES),
-        "method": args.method or prev["method"],
-        "algorithmic_bytes_per_launch": prev["algorithmic_bytes_per_launch"],
-        "traffic_bytes_per_launch": {"2": c["FETCH_SIZE"] * 1024 * 2},
-        "valu_wave_instructions_per_launch": {"2": c["SQ_INSTS_VALU"]},
-        "salu_wave_instructions_per_launch": {"2": c["SQ_INSTS_SALU"]},
-        "kernels": {"2": name + " (this round's pass, tools/final_measure.sh)"},
-        "carried_over_from_" + os.path.basename(args.prev): {"traffic_bytes_per_launch": {k: v for k, v in prev["traffic_bytes_per_launch"].items() if k != "2"},
-                                                              "note": "schedules 0 and 1: kernels unchanged since the pass that measured them; not reported by bench.py (its guard wants this round's hash)"},
-    }
-    if args.clock_held:
-        out["clock_held_GHz"] = {"2": args.clock_held}
-        out["note_clock"] = "in-kernel shader clock of the tiled kernel on this workload (tools/scan_clock.py on a -DNLSH_SCAN_TRACE -DNLSH_SCAN_TRACE_CLOCK build), median over workgroups longer than 20 us"
+    out = {"kernel_source_sha256": bench.kernel_source_hash(), "kernel_sources": list(bench.KERNEL_SOURCES), "method": args.method, "entries": {}}
+    for spec in args.entry:
+        parts = spec.split(":")
+        pmc = json.load(open(parts[0]))
+        line = json.loads([ln for ln in open(parts[1]).read().splitlines() if ln.startswith("{")][-1])
+        kern = {0: "scan_kernel", 1: "bscan2_kernel", 2: "bscan3_kernel"}[line["config"]["shape"]["algo"]]
+        name = max((k for k in pmc if kern in k), key=lambda k: pmc[k].get("SQ_INSTS_VALU", 0))
+        c = pmc[name]
+        ent = {"workload": line["config"]["shape"], "kernel": name, "traffic_bytes_per_launch": c["FETCH_SIZE"] * 1024 * 2,
+               "valu_wave_instructions_per_launch": c.get("SQ_INSTS_VALU"), "salu_wave_instructions_per_launch": c.get("SQ_INSTS_SALU"),
+               "sq_wave_cycles": c.get("SQ_WAVE_CYCLES"), "sq_wait_any": c.get("SQ_WAIT_ANY"),
+               "distinct_candidate_row_bytes_per_launch": line["roofline"].get("distinct_candidate_row_bytes_per_launch"),
+               "algorithmic_bytes_per_launch": line["roofline"]["algorithmic_bytes_per_launch"]}
+        if len(parts) > 2:
+            ent["clock_held_GHz"] = float(parts[2])
+            ent["note_clock"] = "in-kernel shader clock of the tiled kernel on this workload (tools/scan_clock.py on a -DNLSH_SCAN_TRACE -DNLSH_SCAN_TRACE_CLOCK build), median over workgroups longer than 20 us"
+        out["entries"][line["config"]["traffic_key"]] = ent
     print(json.dumps(out, indent=1))
 
 

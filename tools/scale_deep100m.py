@@ -77,6 +77,14 @@ def main():
     ap.add_argument("--shard", default="buckets", choices=["buckets", "rows"])
     ap.add_argument("--save-hash", default="", help="write the trained hash as a portable .npz checkpoint (rank 0)")
     ap.add_argument("--load-hash", default="", help="skip training: load a checkpoint written by --save-hash")
+    ap.add_argument("--pipeline", default="on", choices=["on", "off"],
+                    help="on: batches through the three-stage pipeline (what a serving loop runs; queries/s is quoted on it).  off: every kernel of a "
+                         "step back to back on one stream -- the scan kernel alone on the chip, which is the region a roofline figure and a "
+                         "rocprofv3 --pmc pass should be taken in")
+    ap.add_argument("--l2-form", default="exact", choices=["exact", "folded"])
+    ap.add_argument("--window", type=int, default=None, help="row window of the tiled schedule's small-bucket packing (default: the facade's)")
+    ap.add_argument("--pmc-summary", default="", help="tools/pmc_summary.py output of a rocprofv3 --pmc pass over THIS command (same arguments, --pipeline off): "
+                                                      "fills roofline.traffic / valu counters of the line (bytes = FETCH_SIZE KB x 1024 x 2, MI355X_MICROARCH.md)")
     args = ap.parse_args()
     import torch.distributed as dist
     from nlsh_amd import training
@@ -130,7 +138,8 @@ def main():
 
     torch.cuda.synchronize()
     t0 = time.time()
-    sharded = ShardedIndexer(hashing, corpus, SIFT.distance, id_base=lo, shard=args.shard, compat=H <= 16)
+    sharded = ShardedIndexer(hashing, corpus, SIFT.distance, id_base=lo, shard=args.shard, compat=H <= 16, l2_form=args.l2_form,
+                             window_rows=args.window)
     indexer = sharded.local
     if indexer._candidate_vectors_gpu is not corpus:
         del corpus                                                       # the bucket partition owns its own copy of the rows
@@ -143,26 +152,53 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for a, b in ev:
         a.record(); b.record()
-    pipe = QueryPipeline(indexer, queries, k=k, hash_times=P, depth=3, want_keys=True,
-                         exchange=(lambda k64, nc: gather_and_merge(k64, nc, k)) if world > 1 else None)
-    pipe.submit(queries, seed=1)
-    pipe.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    pipe = None
+    if args.pipeline == "on":
+        pipe = QueryPipeline(indexer, queries, k=k, hash_times=P, depth=3, want_keys=True,
+                             exchange=(lambda k64, nc: gather_and_merge(k64, nc, k)) if world > 1 else None)
+
+    def step(i, events=None):
+        if pipe is not None:
+            return pipe.submit(queries, seed=1, events=events)
+        d_, i_, n_, k64 = indexer.query_tensors(queries, k=k, hash_times=P, seed=1, want_keys=world > 1, check=False, events=events)
+        return gather_and_merge(k64, n_, k) if world > 1 else (d_, i_, n_)
+
+    def drain():
+        if pipe is not None:
+            pipe.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    if pipe is None:
+        indexer.query_tensors(queries, k=k, hash_times=P, seed=1, check=True)   # sizes the task table (the pipeline's constructor does it too)
+    step(-1)
+    drain()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        out = pipe.submit(queries, seed=1, events=ev[i])
-    pipe.synchronize()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+        out = step(i, events=ev[i])
+    drain()
     elapsed = time.perf_counter() - t0
-    assert not pipe.overflowed()
+    if pipe is not None:
+        assert not pipe.overflowed()
+    else:
+        assert int(indexer.last_status.cpu()[1]) == 0, "task table overflow inside the timed region"
+    algo = pipe.algo if pipe is not None else int(indexer.last_algo)
     dist_, idx, nc = out[:3]
     scan_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     sum_c_local = int(indexer.query_tensors(queries, k=k, hash_times=P, seed=1, check=False)[2].long().sum().item())
     sum_c = int(nc.long().sum().item())
+    # rows of the buckets the batch probes at all, each once (bench.py: the bucket-major schedules' algorithmic bytes)
+    kk, nn = indexer.hash_device(queries, hash_times=P, seed=1)
+    pos = torch.searchsorted(indexer.uniq_keys, kk.clamp(min=int(indexer.uniq_keys[0]), max=int(indexer.uniq_keys[-1]))).clamp(max=indexer.n_buckets - 1)
+    hit = (indexer.uniq_keys[pos] == kk) & (torch.arange(kk.shape[1], device=dev)[None, :] < nn[:, None])
+    unique_bytes = 4.0 * d * float((indexer.offsets[1:] - indexer.offsets[:-1]).long()[torch.unique(pos[hit])].sum().item())
+    del kk, nn, pos, hit
+    traffic, valu_insts, salu_insts = None, None, None
+    if args.pmc_summary:
+        pm = json.load(open(args.pmc_summary))
+        name = next(kn for kn in pm if "bscan" in kn or "scan_kernel" in kn)
+        traffic, valu_insts, salu_insts = pm[name]["FETCH_SIZE"] * 1024 * 2, pm[name].get("SQ_INSTS_VALU"), pm[name].get("SQ_INSTS_SALU")
 
     if rank == 0:
         # properties (size independent): ascending, distances of the returned ids (rows regenerated from their ids)
@@ -177,36 +213,50 @@ def main():
         assert bool(((dist_[:256] - ref).abs() <= 2e-5 * ref.clamp(min=1.0))[ok[:256]].all()), "distance mismatch"
         # recall on a sample (chunked brute force over all N rows, regenerated chunk by chunk)
         R = min(args.recall_queries, Q)
-        qs = queries[:R]
-        best_d = torch.full((R, k), float("inf"), device=dev)
-        best_i = torch.full((R, k), -1, dtype=torch.int64, device=dev)
-        qq = (qs * qs).sum(1)[:, None]
-        for ci in range((N + CHUNK - 1) // CHUNK):
-            c = deep_chunk(params, ci, CHUNK, d, 1234, dev)[: min(CHUNK, N - ci * CHUNK)]
-            dd = qq - 2.0 * (qs @ c.T) + (c * c).sum(1)[None, :]
-            td, ti = dd.topk(k, dim=1, largest=False)
-            cat_d, cat_i = torch.cat([best_d, td], 1), torch.cat([best_i, ti + ci * CHUNK], 1)
-            o = cat_d.topk(k, dim=1, largest=False).indices
-            best_d, best_i = cat_d.gather(1, o), cat_i.gather(1, o)
-        recall = float(np.mean(calculate_recall(list(best_i.cpu().numpy()), [r[r >= 0].tolist() for r in idx[:R].cpu().numpy()])))
+        recall = None
+        if R > 0:
+            qs = queries[:R]
+            best_d = torch.full((R, k), float("inf"), device=dev)
+            best_i = torch.full((R, k), -1, dtype=torch.int64, device=dev)
+            qq = (qs * qs).sum(1)[:, None]
+            for ci in range((N + CHUNK - 1) // CHUNK):
+                c = deep_chunk(params, ci, CHUNK, d, 1234, dev)[: min(CHUNK, N - ci * CHUNK)]
+                dd = qq - 2.0 * (qs @ c.T) + (c * c).sum(1)[None, :]
+                td, ti = dd.topk(k, dim=1, largest=False)
+                cat_d, cat_i = torch.cat([best_d, td], 1), torch.cat([best_i, ti + ci * CHUNK], 1)
+                o = cat_d.topk(k, dim=1, largest=False).indices
+                best_d, best_i = cat_d.gather(1, o), cat_i.gather(1, o)
+            recall = float(np.mean(calculate_recall(list(best_i.cpu().numpy()), [r[r >= 0].tolist() for r in idx[:R].cpu().numpy()])))
         print(json.dumps({
             "workload": f"configs[4]: Deep100M-shaped, N={N} d={d} Q={Q} H={H} k={k} hash_times={P}, {world} rank(s), corpus {args.shard} sharded",
             "corpus_gb": N * d * 4 / 1e9, "generate_s": gen_s, "train_s": train_s, "index_build_s": build_s,
             "rank0_rows": int(indexer._candidate_vectors_gpu.shape[0]), "rank0_buckets": stats["n_indexes"], "bucket_mean": stats["mean"],
             "bucket_max": stats["max"], "queries_per_s": Q * args.steps / elapsed, "ms_per_step": 1e3 * elapsed / args.steps,
-            "step_driver": "three-stage pipeline",
-            "scan_kernel": {0: "query-major", 1: "bucket-major", 2: "bucket-major LDS-tiled"}[pipe.algo],
+            "step_driver": "three-stage pipeline" if pipe is not None else "sequential: every kernel of a step back to back on one stream",
+            "scan_kernel": {0: "query-major", 1: "bucket-major", 2: "bucket-major LDS-tiled"}[algo],
             "rank0_scan_ms": scan_ms, "mean_candidates_per_query": sum_c / Q,
             "rank0_algorithmic_GBps": 4.0 * d * sum_c_local / (scan_ms * 1e-3) / 1e9,
-            # same accounting as bench.py: the bucket-major schedules fetch a row once per query group, fp32 VALU issue binds
-            # (3 flop per element: (q-c), +eps, fma; peak 157.3 TF); the query-major schedule re-reads rows per query (HBM, 8 TB/s)
+            # same accounting as bench.py: the bucket-major schedules share a fetched row between the queries of a group, so the roof is the
+            # larger of pair flops / fp32 vector peak (3 flop per element: (q-c), +eps, fma; 157.3 TF) and distinct-candidate-row bytes /
+            # HBM peak; the query-major schedule re-reads rows per query (HBM on 4 d sum C_q, 8 TB/s)
             "roofline": ({"bound": "hbm", "achieved": 4.0 * d * sum_c_local / (scan_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                          "frac": 4.0 * d * sum_c_local / (scan_ms * 1e-3) / 1e9 / 8000.0} if pipe.algo == 0 else
-                         {"bound": "valu", "achieved": 3.0 * d * sum_c_local / (scan_ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                          "frac": 3.0 * d * sum_c_local / (scan_ms * 1e-3) / 1e12 / 157.3}) | {
-                "kernel": {0: "scan_kernel", 1: "bscan2_kernel", 2: "bscan3_kernel"}[pipe.algo], "avg_launch_ms": scan_ms,
-                "sum_candidates_per_launch": sum_c_local, "algorithmic_bytes_per_launch": 4.0 * d * sum_c_local, "traffic": None,
-                "note": "scan kernel timed with HIP events inside the three-stage pipeline (shares the chip with the neighbouring batches' small kernels)"},
+                          "frac": 4.0 * d * sum_c_local / (scan_ms * 1e-3) / 1e9 / 8000.0} if algo == 0 else
+                         ({"bound": "valu", "achieved": (3.0 if args.l2_form == "exact" else 3.0) * d * sum_c_local / (scan_ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                           "frac": 3.0 * d * sum_c_local / (scan_ms * 1e-3) / 1e12 / 157.3}
+                          if 1.5 * 3.0 * d * sum_c_local / 1e12 / 157.3 >= unique_bytes / 1e9 / 8000.0 else
+                          {"bound": "hbm", "achieved": unique_bytes / (scan_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                           "frac": unique_bytes / (scan_ms * 1e-3) / 1e9 / 8000.0})) | {
+                "kernel": {0: "scan_kernel", 1: "bscan2_kernel", 2: "bscan3_kernel"}[algo], "avg_launch_ms": scan_ms,
+                "sum_candidates_per_launch": sum_c_local, "algorithmic_bytes_per_launch": 4.0 * d * sum_c_local,
+                "distinct_candidate_row_bytes_per_launch": unique_bytes, "valu_frac": 3.0 * d * sum_c_local / (scan_ms * 1e-3) / 1e12 / 157.3,
+                "hbm_frac_of_distinct_candidate_rows": unique_bytes / (scan_ms * 1e-3) / 1e9 / 8000.0,
+                "traffic": traffic, "traffic_source": (f"rocprofv3 --pmc pass over this command ({os.path.basename(args.pmc_summary)}): FETCH_SIZE KB x 1024 x 2" if traffic else None),
+                "valu_wave_instructions_per_launch": valu_insts, "salu_wave_instructions_per_launch": salu_insts,
+                "valu_issue_frac": (valu_insts * 2.0 / (1024 * scan_ms * 1e-3 * 2.4e9)) if valu_insts else None,
+                "l2_form": args.l2_form, "window_rows": int(indexer.last_window),
+                "note": ("scan kernel timed with HIP events in a SEQUENTIAL region: every kernel of a step back to back on one stream, the scan alone on the chip"
+                         if pipe is None else
+                         "scan kernel timed with HIP events inside the three-stage pipeline (shares the chip with the neighbouring batches' small kernels)")},
             "recall_at_10_on_sample": recall, "recall_sample": R, "properties": "ascending, distances vs torch on regenerated rows: ok",
             "rank0_peak_mem_gb": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
     if world > 1:
