@@ -897,13 +897,13 @@ __device__ __forceinline__ void l2_task_nt(int ntile, float4 *tile, const float4
 
 // Merge of ONE query's partial lists into its final top-k (one wavefront; `sc` = 64 u64 of LDS scratch owned by the wave).
 __device__ __forceinline__ void merge_query(const BArgs &a, long long q, int lane, uint64_t *sc) {
-    int nk = __builtin_amdgcn_readfirstlane(a.nkeys[q]);
-    nk = nk < 0 ? 0 : (nk > a.P ? a.P : nk);
-    // lane p holds probe p's record (written by bscatter): where its partial lists are
+    // lane p holds probe p's record (written by bscatter): where its partial lists are.  bscatter writes a record for EVERY slot of
+    // the [Q, P] table -- zeros for slots past the query's key count, for repeated keys and for keys without a bucket -- so the key
+    // count is not needed here (r04: its load sat in front of the record load, one dependent round trip per wave)
     int ns_l = 0, j_l = 0, ng_l = 0;
     long long t0_l = 0;
     int size_l = 0;
-    if (lane < nk) {
+    if (lane < a.P) {
         const int4 rec = a.prec[q * a.P + lane];
         t0_l = rec.x; j_l = rec.y; size_l = rec.z; ng_l = rec.w;
         ns_l = (size_l + a.seg - 1) / a.seg;
@@ -1223,13 +1223,14 @@ __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
     // lists); this per-bucket check catches the rest (stale counts that cancel in the sum mis-size individual lists: every
     // access stays in bounds -- clamped query ids, guarded slots -- but the lists are wrong), so a violated contract is
     // ALWAYS reported (status[1] = 2), never a silently wrong result.
-    for (long long b = (long long)blockIdx.x * 256 + threadIdx.x; b < a.nb; b += (long long)gridDim.x * 256)
-        if (a.bcount[b] != 0) a.status[1] = 2;
+    // (the counters are requested first and looked at last: the check must not sit in front of the merge's own dependent loads)
+    int stale = 0;
+    for (long long b = (long long)blockIdx.x * 256 + threadIdx.x; b < a.nb; b += (long long)gridDim.x * 256) stale |= a.bcount[b];
     const int lane = threadIdx.x & 63;
     const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= a.Q) return;
     __shared__ uint64_t scratch[4][64];
-    merge_query(a, q, lane, scratch[threadIdx.x >> 6]);
+    if (q < a.Q) merge_query(a, q, lane, scratch[threadIdx.x >> 6]);
+    if (stale != 0) a.status[1] = 2;
 }
 
 #ifndef NLSH_TILED_QB
@@ -1352,7 +1353,9 @@ int bucket_scan_run(const BucketScanCall &c) {
         if (c.tiled) {
             // QW = 4 queries per wave (SGPR budget: two chunks x QW x 4 scalar values in flight), NW = 4 waves
             // one workgroup per task; the chunked XCD map works on 8 x 16 ids.  (Persistent workgroups pulling tasks from a
-            // per-XCD queue were measured three ways in r02 -- 0.447 / 0.423 / 0.350 ms against 0.283 ms: DESIGN.md 4.2.)
+            // per-XCD queue were measured three ways in r02 -- 0.447 / 0.423 / 0.350 ms against 0.283 ms; r04: 2 / 4 / 8 consecutive
+            // task ids per workgroup, 79 VGPRs, +3 / +10 / +25 % on the headline and no better on the small-bucket workloads:
+            // profiles/r04_tasks_per_workgroup_ab.txt, DESIGN.md appendix A.)
             const unsigned grid = (unsigned)((c.max_tasks + 127) / 128 * 128);
             if (metric == NLSH_METRIC_L2_EPS) hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_L2_EPS, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
             else if (metric == NLSH_METRIC_L2_EPS_FOLDED) hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_L2_EPS_FOLDED, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);

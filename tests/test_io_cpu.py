@@ -102,3 +102,72 @@ def test_dataset_classes_read_the_path_they_are_given(tmp_path):
     syn = data.SyntheticSIFT(n_train=500, n_test=10, dim=32, k=5, unit_norm=True, with_train_knn=True)
     syn.load()
     assert syn.training.shape == (500, 32) and syn.ground_truth.shape == (10, 5) and syn.training_self_knn.shape == (500, 5)
+
+
+def test_hdf5_branch_through_a_stand_in_h5py_module(tmp_path, monkeypatch):
+    """The ann-benchmarks HDF5 branch (`io.load_hdf5`, what nlsh/data.py:17-46,114-138 reads) cannot meet a real file here -- h5py is
+    not in this image -- so it is driven through a stand-in module with h5py's surface for this path (`File(path, "r")` as a context
+    manager, `in`, `f[name]` -> array-like) backed by an .npz: dataset names, dtypes, the optional `distances` / `train_knn`, the
+    standardise / unit-sphere options of the dataset classes and the missing-`train_knn` error are OUR code and are exercised; h5py's
+    own parsing is not (it stays unverified until a real file is supplied: DESIGN.md 7)."""
+    import sys
+    import types
+    from nlsh_amd import data, io
+    rng = np.random.default_rng(3)
+    arrays = {"train": rng.standard_normal((50, 7)), "test": rng.standard_normal((9, 7)).astype(np.float32),
+              "neighbors": rng.integers(0, 50, (9, 5)).astype(np.int32), "distances": rng.random((9, 5)).astype(np.float32),
+              "train_knn": rng.integers(0, 50, (50, 4))}
+
+    def fake_module(names):
+        np.savez(tmp_path / "store.npz", **{n: arrays[n] for n in names})
+
+        class File:
+            def __init__(self, path, mode="r"):
+                assert mode == "r" and str(path).endswith(".hdf5")
+                self._z = np.load(tmp_path / "store.npz")
+
+            def __enter__(self):
+                return self
+
+            def __exit__(self, *exc):
+                self._z.close()
+                return False
+
+            def __contains__(self, name):
+                return name in self._z.files
+
+            def __getitem__(self, name):
+                return self._z[name]
+        mod = types.ModuleType("h5py")
+        mod.File = File
+        return mod
+
+    path = tmp_path / "glove-7-angular.hdf5"
+    path.write_bytes(b"stand-in")
+    monkeypatch.setitem(sys.modules, "h5py", fake_module(list(arrays)))
+    got = io.load_hdf5(path, with_train_knn=True)
+    assert got["training"].dtype == np.float32 and np.array_equal(got["training"], arrays["train"].astype(np.float32))
+    assert np.array_equal(got["testing"], arrays["test"]) and np.array_equal(got["ground_truth"], arrays["neighbors"])
+    assert np.array_equal(got["ground_truth_distances"], arrays["distances"]) and np.array_equal(got["training_self_knn"], arrays["train_knn"])
+    assert "training_self_knn" not in io.load_hdf5(path)                      # only on request (precompute.py:91-97 writes it)
+    ds = data.Glove(str(path), unit_norm=True, unit_ball=True)
+    with pytest.raises(ValueError):
+        ds.training                                                           # nlsh/data.py:48-51: not prepared before load()
+    ds.load()
+    assert ds.dim == 7 and np.allclose(np.linalg.norm(ds.training, axis=1), 1.0, atol=1e-5)   # standardised, then on the unit sphere
+    assert np.array_equal(ds.ground_truth, arrays["neighbors"]) and np.array_equal(ds.training_self_knn, arrays["train_knn"])
+    sift = data.SIFT(str(path), unit_norm=True)
+    sift.load()
+    assert np.allclose(sift.training.mean(0), 0.0, atol=1e-5) and np.allclose(sift.training.std(0), 1.0, atol=1e-4)
+    # a file without the optional datasets: no distances key, and the reference's AttributeError for a missing train_knn
+    monkeypatch.setitem(sys.modules, "h5py", fake_module(["train", "test", "neighbors"]))
+    bare = io.load_hdf5(path, with_train_knn=True)
+    assert set(bare) == {"training", "testing", "ground_truth"}
+    plain = data.SIFT(str(path))
+    plain.load()
+    with pytest.raises(AttributeError):
+        plain.training_self_knn
+    # and without any h5py the reader says so instead of substituting something
+    monkeypatch.setitem(sys.modules, "h5py", None)
+    with pytest.raises(ImportError):
+        io.load_hdf5(path)

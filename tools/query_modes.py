@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Same-box comparison of the host-side modes of `Indexer.query()` on the headline workload (ms per call over a loop that keeps
-only the latest result, like bench.py's protocol region): numpy `tolist()` vs csrc/fastlists.c (inner lists untracked by the GC),
-`promote_results` and `defer_result_release` on / off, 1 or 2 row ranges."""
+only the latest result, like bench.py's protocol region): numpy `tolist()` vs csrc/fastlists.c, the opt-ins
+(`untracked_results`, `promote_results`, `defer_result_release`) on / off, 1 to 4 row ranges."""
 import json
 import os
 import sys
@@ -25,9 +25,9 @@ qb = [torch.from_numpy(synth.standardise(synth.sift_manifold(Q, d, seed=synth.SE
 fast = ixmod._rows_to_lists
 
 
-def run(builder, promote, defer, chunks, n=60):
+def run(builder, promote, defer, chunks, untrack=False, n=60):
     ixmod._rows_to_lists = builder
-    Indexer.promote_results, Indexer.defer_result_release, Indexer.query_chunks = promote, defer, chunks
+    Indexer.promote_results, Indexer.defer_result_release, Indexer.query_chunks, Indexer.untracked_results = promote, defer, chunks, untrack
     keep = None
     for i in range(8):
         keep = ix.query(qb[i % 4], 10, 10)
@@ -41,15 +41,18 @@ def run(builder, promote, defer, chunks, n=60):
 
 rows = []
 for rep in range(2):
-    for name, builder, promote, defer, chunks in (
-            ("tolist, defaults (2 ranges)", None, False, False, None),
-            ("tolist + promote + defer", None, True, True, None),
-            ("fastlists, defaults (2 ranges)", fast, False, False, None),
-            ("fastlists, defaults, 1 range", fast, False, False, 1),
-            ("fastlists + defer", fast, False, True, None),
-            ("fastlists + promote + defer", fast, True, True, None)):
+    for name, builder, promote, defer, chunks, untrack in (
+            ("tolist, defaults (2 ranges)", None, False, False, None, False),
+            ("fastlists, defaults (tracked rows, 2 ranges)", fast, False, False, None, False),
+            ("fastlists, defaults, 1 range", fast, False, False, 1, False),
+            ("fastlists, defaults, 3 ranges", fast, False, False, 3, False),
+            ("fastlists, defaults, 4 ranges", fast, False, False, 4, False),
+            ("fastlists + untracked rows", fast, False, False, None, True),
+            ("fastlists + defer", fast, False, True, None, False),
+            ("fastlists + untracked + defer (bench.py's opt-in region)", fast, False, True, None, True),
+            ("fastlists + untracked + promote + defer", fast, True, True, None, True)):
         if builder is None or fast is not None:
-            rows.append((name, round(run(builder, promote, defer, chunks), 4)))
-Indexer.promote_results, Indexer.defer_result_release, Indexer.query_chunks = False, False, None
+            rows.append((name, round(run(builder, promote, defer, chunks, untrack), 4)))
+Indexer.promote_results, Indexer.defer_result_release, Indexer.query_chunks, Indexer.untracked_results = False, False, None, False
 ixmod._rows_to_lists = fast
 print(json.dumps(rows))
