@@ -193,9 +193,11 @@ int nlsh_scan_topk(const float *corpus_sorted, int64_t row_stride, int d, const 
 
 /* Diagnostic, for tests of the bucket-major schedules (algo 1, 2): byte offsets, inside a workspace of this shape, of the
  * task table the PLAN phase leaves there -- int32 [status[0]][4] = {first pair of the query group, queries in the group,
- * first corpus row of the segment, rows in the segment} -- and (algo 2 only) of the tasks' query ids, int32 [max_tasks][16], and
- * of each (task, query)'s row range inside the task's rows, int32 [max_tasks][16] = lo | hi << 16 (the rows of the query's own
- * bucket: the whole segment without cells, the bucket's slice of a shared window with them).  Any out pointer may be NULL.
+ * first corpus row of the segment, rows in the segment} -- and (algo 2 only) of the tasks' per-slot records, ONE interleaved table
+ * int32 [max_tasks][16][2] = {query id, row range lo | hi << 16}: *task_queries_offset is the table's offset (the id of (task, slot)
+ * sits at + (task * 16 + slot) * 8), *task_ranges_offset = *task_queries_offset + 4 (the same stride of 8 bytes); the range is the
+ * rows of the query's own bucket inside the task's rows: the whole segment without cells, the bucket's slice of a shared window
+ * with them.  Any out pointer may be NULL.
  * No reference counterpart: the reference has no schedule (it walks `for key in index_keys`, nlsh/indexer.py:66). */
 int nlsh_scan_workspace_layout(int64_t Q, int P, int k, int64_t max_tasks, int64_t n_buckets, int d, int algo,
                                size_t *task_table_offset, size_t *task_queries_offset, size_t *task_ranges_offset);

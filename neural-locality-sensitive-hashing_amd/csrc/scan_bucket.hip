@@ -116,9 +116,10 @@ struct BArgs {
     int32_t *pbkt, *inv_q, *bcount, *pairoff, *taskoff, *bgroups, *counters;   // bcount / pairoff / taskoff / bgroups are per CELL
     int4 *prec;  // [Q*P] per (query, probe): {first task of its query group, slot in the group, bucket rows, query groups}; .z = 0: no bucket
     int4 *task;
-    int32_t *task_q;   // tiled schedule: [max_tasks][16] query ids of every task (its group's slice of inv_q, repeated per row segment)
-    int32_t *task_r;   // tiled schedule: [max_tasks][16] row range of every (task, query) inside the task's rows, lo | hi << 16: the rows of the
-                       // query's bucket (a whole segment of a big bucket; the bucket's slice of a shared window)
+    int2 *task_qr;     // tiled schedule: [max_tasks][16] {query id, row range lo | hi << 16} of every (task, slot): the task's group's slice of
+                       // inv_q, repeated per row segment, and the rows of the query's bucket inside the task's rows (a whole segment of a
+                       // big bucket; the bucket's slice of a shared window).  ONE 8-byte record: one store in bscatter, one load in the scan
+    int32_t *pcell;    // [Q*P] cell of every (query, probe) pair's bucket (bplan looked it up for the counter: bscatter need not again)
     uint64_t *partial;
     long long max_tasks;
     const int32_t *border;     // [nc] schedule order of the cells (largest first) or nullptr = CSR order
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void bplan_kernel(BArgs a, int stride) {
     __syncthreads();
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx == 0) { a.status[0] = 0; a.status[1] = 0; }   // per-batch initialisation rides along (no separate launch)
-    int b = -1;
+    int b = -1, cell = -1;
     if (idx < a.Q * a.P) {
         const long long q = idx / a.P;
         const int p = (int)(idx - q * a.P);
@@ -171,12 +172,14 @@ __global__ __launch_bounds__(256) void bplan_kernel(BArgs a, int stride) {
                     const int sz = a.offsets[lo + 1] - a.offsets[lo];
                     if (sz > 0) {
                         b = lo;
-                        atomicAdd(&a.bcount[a.cell_of ? a.cell_of[lo] : lo], 1);
+                        cell = a.cell_of ? a.cell_of[lo] : lo;
+                        atomicAdd(&a.bcount[cell], 1);
                     }
                 }
             }
         }
         a.pbkt[idx] = b;
+        a.pcell[idx] = cell;
     }
     // pairs this block added to the counters: bscan_kernel holds the counters' sum against the sum of these, which is how
     // a workspace head that was not zero on entry (workspace contract, nlsh_hip.h) is caught instead of trusted
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(256) void bscatter_kernel(BArgs a) {
         a.prec[idx] = make_int4(0, 0, 0, 0);
         return;
     }
-    const int c = a.cell_of ? a.cell_of[b] : b;
+    const int c = a.pcell[idx];
     const int rel = atomicSub(&a.bcount[c], 1) - 1;  // slot of this query in the cell's pair list
     if (rel < 0) {   // the counter started below zero-plus-this-batch's-pairs: a stale negative count (workspace contract); no slot exists
         a.status[1] = 2;
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(256) void bscatter_kernel(BArgs a) {
     const int row0 = a.offsets[b], size = a.offsets[b + 1] - row0;
     const int t0 = a.taskoff[c] + gi, ng = a.bgroups[c];
     a.prec[idx] = make_int4(t0, rel - gi * a.QB, size, ng);
-    if (a.task_q) {
+    if (a.task_qr) {
         // the tiled scan reads a task's query ids from the task's own record (address known from the task id alone: the
         // ids arrive with the descriptor instead of one dependent round trip later); one copy per row segment
         const int ns = (size + a.seg - 1) / a.seg;
@@ -357,8 +360,7 @@ __global__ __launch_bounds__(256) void bscatter_kernel(BArgs a) {
             const long long tt = (long long)t0 + (long long)si * ng;
             if (tt >= a.max_tasks) break;
             const int lo = max(lo0 - si * a.seg, 0), hi = min(lo0 + size - si * a.seg, a.seg);   // the bucket's rows inside segment si
-            a.task_q[tt * a.QB + (rel - gi * a.QB)] = (int32_t)(idx / a.P);
-            a.task_r[tt * a.QB + (rel - gi * a.QB)] = lo | (hi << 16);
+            a.task_qr[tt * a.QB + (rel - gi * a.QB)] = make_int2((int32_t)(idx / a.P), lo | (hi << 16));
         }
     }
 }
@@ -1203,13 +1205,13 @@ __global__ __launch_bounds__(64 * NW, NLSH_TILED_MIN_WAVES) void bscan3_kernel(B
     // less in front of every task
     const long long tc = t < a.max_tasks ? t : a.max_tasks - 1;
     const int4 desc = a.task[tc];
-    int qid_v[QW];                                    // the task's query ids: address known from the task id alone
+    int qid_v[QW], rng_v[QW];                         // the task's query ids and each query's row range inside the task's rows: address known from the task id alone
 #pragma unroll
-    for (int jq = 0; jq < QW; ++jq)   // slots >= nq hold garbage, never used; clamped into [0, Q) so that a slot a stale counter invented (bmerge flags it) addresses nothing outside the queries
-        qid_v[jq] = min(max(a.task_q[tc * (QW * NW) + NLSH_SLOT(wave, jq)], 0), (int)a.Q - 1);
-    int rng_v[QW];                                    // and each query's row range inside the task's rows
-#pragma unroll
-    for (int jq = 0; jq < QW; ++jq) rng_v[jq] = a.task_r[tc * (QW * NW) + NLSH_SLOT(wave, jq)];
+    for (int jq = 0; jq < QW; ++jq) {   // slots >= nq hold garbage, never used; ids clamped into [0, Q) so that a slot a stale counter invented (bmerge flags it) addresses nothing outside the queries
+        const int2 qr = a.task_qr[tc * (QW * NW) + NLSH_SLOT(wave, jq)];
+        qid_v[jq] = min(max(qr.x, 0), (int)a.Q - 1);
+        rng_v[jq] = qr.y;
+    }
     if (t >= ntasks) return;
     if (NLSH_ABLATE == 9) return;   // diagnostic: every workgroup leaves after its descriptor loads (what dispatching the grid costs)
     if (NLSH_ABLATE == 8 && desc.y <= NLSH_ABLATE_NQ) return;   // diagnostic: tasks with few queries vanish (what the low-density tasks cost)
@@ -1243,7 +1245,7 @@ constexpr int TILED_QB = NLSH_TILED_QB;  // queries per task of the tiled schedu
 constexpr int TILED_TPS = NLSH_TILED_TPS;  // 64-row tiles per task of the tiled schedule (segment = 64*TPS rows)
 
 struct BWs {
-    size_t pbkt, prec, inv_q, bcount, pairoff, taskoff, bgroups, counters, btot, hits, task, task_q, task_r, partial, qpad, tauq, total;
+    size_t pbkt, prec, inv_q, bcount, pairoff, taskoff, bgroups, counters, btot, hits, task, task_qr, pcell, partial, qpad, tauq, total;
 };
 static void blayout(long long Q, int P, int k, long long max_tasks, long long nb, int d, bool tiled, BWs *w) {
     size_t o = 0;
@@ -1259,8 +1261,8 @@ static void blayout(long long Q, int P, int k, long long max_tasks, long long nb
     w->btot = o;     o += ws_align((size_t)((nb + 255) / 256 + 1) * 12);
     w->hits = o;     o += ws_align((size_t)((Q * P + 255) / 256 + 1) * 4);
     w->task = o;     o += ws_align((size_t)max_tasks * sizeof(int4));
-    w->task_q = o;   o += tiled ? ws_align((size_t)max_tasks * TILED_QB * 4) : 0;
-    w->task_r = o;   o += tiled ? ws_align((size_t)max_tasks * TILED_QB * 4) : 0;
+    w->task_qr = o;  o += tiled ? ws_align((size_t)max_tasks * TILED_QB * 8) : 0;
+    w->pcell = o;    o += ws_align(qp);
     w->partial = o;  o += ws_align((size_t)max_tasks * (tiled ? TILED_QB : 8) * k * 8);
     w->qpad = o;     o += tiled ? ws_align((size_t)Q * ((d + 3) / 4) * 16) : 0;
     w->tauq = o;     o += ws_align((size_t)Q * 8);
@@ -1283,8 +1285,8 @@ extern "C" int nlsh_scan_workspace_layout(int64_t Q, int P, int k, int64_t max_t
     nlsh::BWs w;
     nlsh::blayout(Q, P, k, max_tasks, n_buckets, d, algo == NLSH_SCAN_BUCKET_TILED, &w);
     if (task_table_offset) *task_table_offset = w.task;
-    if (task_queries_offset) *task_queries_offset = w.task_q;
-    if (task_ranges_offset) *task_ranges_offset = w.task_r;
+    if (task_queries_offset) *task_queries_offset = w.task_qr;        // interleaved: {query id, range} pairs, 8 bytes per (task, slot)
+    if (task_ranges_offset) *task_ranges_offset = w.task_qr + 4;
     return NLSH_OK;
 }
 
@@ -1322,7 +1324,7 @@ int bucket_scan_run(const BucketScanCall &c) {
     char *base = (char *)c.workspace;
     a.pbkt = (int32_t *)(base + w.pbkt); a.prec = (int4 *)(base + w.prec); a.inv_q = (int32_t *)(base + w.inv_q);
     a.bcount = (int32_t *)(base + w.bcount); a.pairoff = (int32_t *)(base + w.pairoff); a.taskoff = (int32_t *)(base + w.taskoff); a.bgroups = (int32_t *)(base + w.bgroups);
-    a.counters = (int32_t *)(base + w.counters); a.btot = (int32_t *)(base + w.btot); a.hits = (int32_t *)(base + w.hits); a.border = c.bucket_order; a.task = (int4 *)(base + w.task); a.task_q = c.tiled ? (int32_t *)(base + w.task_q) : nullptr; a.task_r = c.tiled ? (int32_t *)(base + w.task_r) : nullptr; a.partial = (uint64_t *)(base + w.partial);
+    a.counters = (int32_t *)(base + w.counters); a.btot = (int32_t *)(base + w.btot); a.hits = (int32_t *)(base + w.hits); a.border = c.bucket_order; a.task = (int4 *)(base + w.task); a.task_qr = c.tiled ? (int2 *)(base + w.task_qr) : nullptr; a.pcell = (int32_t *)(base + w.pcell); a.partial = (uint64_t *)(base + w.partial);
     a.max_tasks = c.max_tasks;
     a.tauq = (unsigned long long *)(base + w.tauq);
 

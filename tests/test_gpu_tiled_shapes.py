@@ -56,9 +56,9 @@ def _task_table(indexer, Qn, P, k, d, full=False):
     tab = ws[off_task.value:off_task.value + 16 * n_tasks].view(torch.int32).view(-1, 4).cpu().numpy()
     if not full:
         return tab[:, 1], tab[:, 3]
-    tq = ws[off_q.value:off_q.value + 64 * n_tasks].view(torch.int32).view(-1, 16).cpu().numpy()
-    tr = ws[off_r.value:off_r.value + 64 * n_tasks].view(torch.int32).view(-1, 16).cpu().numpy()
-    return tab, tq, tr
+    assert off_r.value == off_q.value + 4                            # one interleaved table of {query id, row range} records
+    qr = ws[off_q.value:off_q.value + 128 * n_tasks].view(torch.int32).view(-1, 16, 2).cpu().numpy()
+    return tab, qr[:, :, 0], qr[:, :, 1]
 
 
 @pytest.mark.parametrize("d", [128, 100, 96, 72])

@@ -311,3 +311,10 @@ def test_deferred_release_never_holds_more_than_two_results():
         Indexer.defer_result_release = False
     ix._keep(([], []))
     assert ix._held == []
+
+
+def test_graft_entry_build_passes_on_cpu():
+    """`__graft_entry__.build()` is the driver's "does it build" check: hipcc cross-compiles gfx950 without a GPU, the library's ABI version
+    must be the header's (r04 bumped it to 2 and the entry point still asserted 1 until this test existed), every declared symbol resolves."""
+    import __graft_entry__ as g
+    g.build()

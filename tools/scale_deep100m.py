@@ -197,7 +197,8 @@ def main():
     traffic, valu_insts, salu_insts = None, None, None
     if args.pmc_summary:
         pm = json.load(open(args.pmc_summary))
-        name = next(kn for kn in pm if "bscan" in kn or "scan_kernel" in kn)
+        kern_name = {0: "scan_kernel", 1: "bscan2_kernel", 2: "bscan3_kernel"}[algo]
+        name = next(kn for kn in pm if kern_name in kn)
         traffic, valu_insts, salu_insts = pm[name]["FETCH_SIZE"] * 1024 * 2, pm[name].get("SQ_INSTS_VALU"), pm[name].get("SQ_INSTS_SALU")
 
     if rank == 0:

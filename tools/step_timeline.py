@@ -5,7 +5,7 @@
     python3 tools/step_timeline.py --parse DIR                                                  # per-kernel offsets / gaps
     python3 tools/step_timeline.py --graph                                                      # eager vs hipGraph replay of one step
 
---parse prints, averaged over the last steps: each kernel's start relative to the step's first kernel, its duration and
+--parse prints, as medians over the last steps: each kernel's start relative to the step's first kernel, its duration and
 the idle gap in front of it (previous kernel's end -> this kernel's start), plus the step period.  --graph captures ONE
 `query_tensors` step (fixed batch, fixed probe seed: kernel arguments are baked into a captured graph) in a
 torch.cuda.CUDAGraph and times its replay against the eager launches: what launch gaps cost, as an upper bound of what a
@@ -34,14 +34,15 @@ if len(sys.argv) > 2 and sys.argv[1] == "--parse":
     names = [r[2] for r in steps[-1]]
     steps = [s for s in steps if [r[2] for r in s] == names]
     print(f"{len(steps)} steps; per kernel: start_us dur_us gap_before_us")
+    med = lambda v: sorted(v)[len(v) // 2]   # noqa: E731  (median: one step that waits for the profiler's buffer flush must not be averaged in)
     for j, nme in enumerate(names):
-        st = sum(s[j][0] - s[0][0] for s in steps) / len(steps) / 1e3
-        du = sum(s[j][1] - s[j][0] for s in steps) / len(steps) / 1e3
-        gp = 0.0 if j == 0 else sum(s[j][0] - s[j - 1][1] for s in steps) / len(steps) / 1e3
+        st = med([s[j][0] - s[0][0] for s in steps]) / 1e3
+        du = med([s[j][1] - s[j][0] for s in steps]) / 1e3
+        gp = 0.0 if j == 0 else med([s[j][0] - s[j - 1][1] for s in steps]) / 1e3
         print(f"  {nme:22s} {st:8.1f} {du:8.1f} {gp:7.1f}")
     per = [(b[0][0] - a[0][0]) / 1e3 for a, b in zip(steps[:-1], steps[1:])]
-    busy = sum(sum(r[1] - r[0] for r in s) for s in steps) / len(steps) / 1e3
-    print(f"step period {sum(per) / max(len(per), 1):.1f} us; kernels busy {busy:.1f} us")
+    busy = med([sum(r[1] - r[0] for r in s) for s in steps]) / 1e3
+    print(f"step period (median) {med(per) if per else 0.0:.1f} us; kernels busy {busy:.1f} us")
     sys.exit(0)
 
 import torch  # noqa: E402
