@@ -25,11 +25,18 @@ N>1: corpus buckets sharded over the ranks (whole buckets per rank, one build-ti
 contiguous row ranges), every rank answers all queries over its shard, one all-gather (RCCL) of the per-rank top-k +
 merge per step ("strong" scaling: total work fixed).
 
-`roofline`: the tiled / wave-level bucket-major schedules fetch a corpus row once per query GROUP, so they are bound by
-fp32 VALU issue, not HBM: bound = "valu", achieved = 3*d*sum(C_q) flop / kernel time against the 157.3 TF fp32 vector
-peak.  The query-major schedule re-reads every row per query: bound = "hbm", achieved = 4*d*sum(C_q) B / kernel time
-against 8 TB/s.  The algorithmic-bytes rate is always reported as `algorithmic_GBps` (not a fraction of anything for
-the bucket-major schedules).  `cpu_baseline` = the CPU restatements timed on this box's host cores on a bounded sample.
+`value` is measured with the facade's DEFAULT settings (what an unmodified Trainer.fit gets); `protocol_qps_opt_in` is the
+same region with the two host-side opt-ins.  `--l2-form folded` prints the complete line on the opt-in
+2-op L2 form instead (config.l2_form).
+
+`roofline`: the query-major schedule re-reads every row per query: bound = "hbm", achieved = 4*d*sum(C_q) B / kernel
+time against 8 TB/s.  The bucket-major schedules share a fetched row between the queries of a group, so two roofs can bind
+them, both on algorithmic quantities measured live: pair flops (3*d*sum(C_q), 2*d for cosine) against the 157.3 TF fp32
+vector peak, and the bytes of the batch's DISTINCT candidate rows against 8 TB/s; bound = "valu" unless the HBM fraction
+exceeds 1.5x the VALU fraction; both fractions are always printed, SURVEY 8(d)'s per-pair byte rate as
+`algorithmic_GBps`.  `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc pass of the SAME workload, schedule,
+row window and kernel sources (profiles/traffic_r04.json), else null.  `cpu_baseline` = the CPU restatements timed on this
+box's host cores on a bounded sample.
 There is no dataset or reference checkpoint offline: data is seeded synthetic (`synth.sift_manifold`) and the hash is
 the one our minimal trainer learned on it (checkpoints/, see config.hash).
 """

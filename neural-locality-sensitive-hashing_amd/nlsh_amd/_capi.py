@@ -21,7 +21,7 @@ PHASE_PLAN, PHASE_SCAN, PHASE_MERGE = 1, 2, 4
 PHASE_ALL = 7
 MAX_ENCODE_PROBES = 128  # nlsh_encode_hash generates up to this many keys per row; the scan takes them in slices of MAX_PROBES
 
-# every symbol include/nlsh_hip.h declares (tests/test_host_cpu.py checks the header against this)
+# every symbol include/nlsh_hip.h declares (tests/test_host_cpu.py::test_capi_library_exports_every_declared_symbol checks the header against this)
 SYMBOLS = (
     "nlsh_abi_version", "nlsh_last_error",
     "nlsh_encoder_packed_floats", "nlsh_encoder_pack", "nlsh_encode_hash", "nlsh_pack_codes",

@@ -1,7 +1,7 @@
 """CPU oracle: restatement of the reference's query-time hot path (numpy + oracle/nlsh_oracle.c).
 
 TEST INFRASTRUCTURE ONLY -- imported by tests/, `__graft_entry__.smoke()` and bench.py's
-`cpu_baseline` leg; the product package never imports it (tests/test_no_oracle_in_product.py).
+`cpu_baseline` leg; the product package never imports it (tests/test_host_cpu.py::test_product_never_references_the_oracle).
 
 Parity pin: checked against golden vectors generated from the unmodified reference
 (tests/golden/make_golden.py, tests/test_oracle_golden.py).  Reference lines restated:

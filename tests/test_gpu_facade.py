@@ -311,3 +311,43 @@ def test_hash_in_train_mode_uses_batch_statistics_like_the_reference():
     a = plain.hash_device(x, n=1)[0].clone()
     plain.train_mode(False)
     assert torch.equal(a, plain.hash_device(x, n=1)[0])
+
+
+def test_indexer_hashes_a_batchnorm_encoder_in_train_mode_batch_by_batch_like_the_reference():
+    """nlsh/indexer.py:40-53: `Indexer.hash` feeds the module `batch_size`-row batches -- in TRAIN mode with BatchNorm that means
+    per-batch statistics, one running-statistics update per batch, and the trailing partial batch on its own statistics with n = 1
+    (one forward over all rows used other statistics).  The index build goes the same way (indexer.py:36-38)."""
+    import copy
+    from nlsh_amd.data import SIFT
+    from nlsh_amd.encoders import MultiLayerRelu
+    from nlsh_amd.hashings import MultivariateBernoulli
+    from nlsh_amd.indexer import Indexer
+    torch.manual_seed(5)
+    d, H, N, bsz = 32, 10, 700, 256
+    x = torch.randn(N, d, device="cuda") * 1.5 + 0.3
+    hashing = MultivariateBernoulli(MultiLayerRelu(d, [24], with_batchnorm=True), H, None)
+    hashing.train_mode(False)
+    ix = Indexer(hashing, x, SIFT.distance)                          # built in eval mode: the fused kernel
+    hashing.train_mode(True)
+    twin = copy.deepcopy(hashing._hasher)                            # same weights, same running statistics, same mode
+    keys, nkeys = ix.hash_device(x, batch_size=bsz, hash_times=1)
+    want = []
+    with torch.no_grad():
+        for lo in range(0, N, bsz):                                  # the reference's loop: 256 + 256 + 188 rows
+            want.append((twin(x[lo:lo + bsz]) > 0.5).int())
+    want = oracle.pack_keys(torch.cat(want).cpu().numpy()[:, None, :], "ref_int16")[:, 0]
+    assert np.array_equal(keys[:, 0].cpu().numpy(), want) and bool((nkeys == 1).all())
+    bn, bn_twin = ([m for m in mod.modules() if isinstance(m, torch.nn.BatchNorm1d)][0] for mod in (hashing._hasher, twin))
+    assert torch.allclose(bn.running_mean, bn_twin.running_mean) and int(bn.num_batches_tracked) == int(bn_twin.num_batches_tracked) == 3
+    # multi-probe: full batches get hash_times keys, the trailing partial batch stays single-probe (F6)
+    keys5, nkeys5 = ix.hash_device(x, batch_size=bsz, hash_times=5)
+    assert keys5.shape == (N, 5) and int(nkeys5[:512].max()) > 1 and bool((nkeys5[512:] == 1).all())
+    # the pipeline runs the fused eval-mode kernel only: it refuses a train-mode BatchNorm hasher instead of hashing with other statistics
+    from nlsh_amd import _capi
+    from nlsh_amd.pipeline import QueryPipeline
+    hashing.train_mode(False)
+    pipe = QueryPipeline(ix, x[:128].contiguous(), k=5, hash_times=2)
+    hashing.train_mode(True)
+    with pytest.raises(_capi.NlshHipError):
+        pipe.submit(x[:128].contiguous())
+    hashing.train_mode(False)

@@ -86,3 +86,17 @@ def test_shipped_tiled_scan_kernels_are_clean():
         assert res["SGPRs Spill"] <= 32, (name, res)
         assert res["Occupancy"] >= 7 and res["VGPRs"] <= 72, (name, res)
         assert res["LDS Size"] <= 22528, (name, res)
+
+
+@needs_hipcc
+def test_diagnostic_switches_exist_only_under_nlsh_diag():
+    """The NLSH_ABLATE / NLSH_NO_STAGE_BARRIER builds remove pieces of the kernel to time the rest: wrong results by design.  They live
+    behind -DNLSH_DIAG (csrc/scan_common.h): a stray -DNLSH_ABLATE on the shipped flags must not compile, and the diagnostic build itself
+    must keep compiling (compile-only: the ablation code does not rot unseen)."""
+    import subprocess
+    src = os.path.join(isa_lint.CSRC, "scan_bucket.hip")
+    base = [isa_lint.HIPCC, *isa_lint.BASE_FLAGS, "--cuda-device-only", "-c", src, "-o", os.devnull]
+    stray = subprocess.run(base + ["-DNLSH_ABLATE=5"], capture_output=True, text=True)
+    assert stray.returncode != 0 and "diagnostic builds only" in stray.stderr
+    diag = subprocess.run(base + ["-DNLSH_DIAG", "-DNLSH_ABLATE=13", "-DNLSH_NO_STAGE_BARRIER=1"], capture_output=True, text=True)
+    assert diag.returncode == 0, diag.stderr[-2000:]
