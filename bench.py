@@ -534,10 +534,11 @@ def main():
                                "the figure that scales is named by scaling_value_key"),
             "protocol_qps_opt_in": Q * steps / elapsed_opt_in,
             # the field of THIS line a scaling study should read: device-resident steps (results left in HBM, incl. the all-gather + merge at N>1);
-            # predicted ceiling from the one-GPU emulation of the per-rank local step (profiles/r03_shard_step_profile.jsonl: 0.360 / 0.224 / 0.166 /
-            # 0.140 ms at 1 / 2 / 4 / 8 shards -> at most 2.6x at N=8 before the exchange: encode + plan + merge are replicated on every rank)
+            # predicted ceiling from the one-GPU emulation of the per-rank pipelined local step (profiles/r04_shard_step_profile_pipelined.jsonl:
+            # 0.291 / 0.170 / 0.123 / 0.097 ms at 1 / 2 / 4 / 8 bucket shards): encode + PLAN + merge are replicated on every rank and, at
+            # 8 shards, the step equals the host's time to enqueue it
             "scaling_value_key": "device_resident_qps",
-            "scaling_ceiling_note": "per-rank local step emulated on one GPU: x1.6 / x2.2 / x2.6 at N = 2 / 4 / 8 before the all-gather (replicated per-batch kernels)",
+            "scaling_ceiling_note": "per-rank pipelined local step emulated on one GPU: x1.7 / x2.4 / x3.0 at N = 2 / 4 / 8 before the all-gather (replicated per-batch kernels; host enqueue time at N = 8)",
             "own_slice_qps": None if elapsed_own is None else Q * steps / elapsed_own,
             "protocol_median_qps": Q / float(np.median(call_s)),
             "protocol_call_ms": [round(1e3 * c, 3) for c in call_s],

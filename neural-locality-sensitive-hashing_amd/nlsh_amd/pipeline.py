@@ -40,7 +40,7 @@ class _Slot:
 class QueryPipeline:
 
     def __init__(self, indexer, sample_queries, k=10, hash_times=10, depth=3, want_keys=False,
-                 exchange: Optional[Callable] = None):
+                 exchange: Optional[Callable] = None, split_front: Optional[bool] = None):
         """`sample_queries`: a batch of the shape every later batch has (sizes the task table with one ordinary,
         checked call).  `exchange(keys64, ncand) -> (dist, idx, ncand)`: the sharded index's all-gather + merge,
         run on the tail stream (needs the 64-bit keys, so it implies want_keys)."""
@@ -56,6 +56,26 @@ class QueryPipeline:
         self.Q, self.d = q.shape
         indexer.query_tensors(q, k=k, hash_times=hash_times, seed=0, check=True)     # sizes indexer._max_tasks
         torch.cuda.synchronize(dev)
+        if split_front is None:
+            # Four stages (the PLAN phase on a stream of its own behind the encode) pay when the front stage -- encode + PLAN, two
+            # latency-bound chains of ~40 us each whatever the shard size -- is about as long as the scan: small shards of a
+            # multi-GPU run.  Measured on the one-GPU emulation of the headline's shards (r04): 1 shard 0.290 -> 0.296 ms per
+            # pipelined step, 4 shards 0.128 -> 0.119, 8 shards 0.108 -> 0.095 (then equal to the host's time to enqueue a step).
+            # Decided from two timed sequential steps of THIS batch shape on THIS index: the whole step against its scan kernel.
+            cur = torch.cuda.current_stream(dev)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            for e in ev:
+                e.record(cur)
+            for _ in range(2):
+                ev[0].record(cur)
+                indexer.query_tensors(q, k=k, hash_times=hash_times, seed=0, check=False, events=(ev[1], ev[2]))
+                ev[3].record(cur)
+            torch.cuda.synchronize(dev)
+            step_ms, scan_ms = ev[0].elapsed_time(ev[3]), ev[1].elapsed_time(ev[2])
+            split_front = scan_ms < 1.25 * 0.8 * max(step_ms - scan_ms, 0.0)   # ~80 % of what is not the scan is the front stage
+        self.split_front = bool(split_front)
+        if self.split_front and depth < 4:
+            depth = 4                                                 # one slot per stage in flight
         self.algo = indexer.last_algo
         self.max_tasks = indexer._max_tasks[indexer._last_tkey]
         ws_bytes = _capi.lib().nlsh_scan_workspace(self.Q, self.P, k, self.max_tasks, indexer.n_buckets, self.d)
@@ -64,6 +84,9 @@ class QueryPipeline:
         self.front = torch.cuda.Stream(device=dev, priority=-1)
         self.mid = torch.cuda.Stream(device=dev, priority=0)
         self.tail = torch.cuda.Stream(device=dev, priority=-1)
+        # split_front: the PLAN phase on a stream of its own behind the encode (four stages): on small shards the front stage
+        # (encode + PLAN, two latency-bound chains of ~40 us each) is the longest one and bounds the pipelined step
+        self.plan = torch.cuda.Stream(device=dev, priority=-1) if self.split_front else None
         self.slots = []
         for _ in range(depth):
             s = _Slot()
@@ -75,7 +98,7 @@ class QueryPipeline:
             s.ncand = torch.empty((self.Q,), dtype=torch.int32, device=dev)
             s.status = torch.zeros((2,), dtype=torch.int32, device=dev)
             s.ws = torch.zeros((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)   # PLAN-phase head must start out zero (include/nlsh_hip.h)
-            s.planned, s.scanned, s.done = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+            s.planned, s.scanned, s.done, s.encoded = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
             s.done.record(torch.cuda.current_stream(dev))
             # everything about the slot's launches that does not change from batch to batch, as plain ints: a submit is
             # four ctypes transitions + six event calls (built per call it cost 125 us of host time per batch, which
@@ -121,16 +144,21 @@ class QueryPipeline:
                 torch.cuda.current_stream(queries.device).wait_stream(front)   # batches in flight still read the old blob
             self._bind_weights()
         front.wait_stream(torch.cuda.current_stream(queries.device))        # the batch may still be in flight there
-        for st in (front, mid, tail):                                       # all three stages read the batch tensor
+        for st in (front, mid, tail) + ((self.plan,) if self.plan is not None else ()):   # every stage reads the batch tensor
             queries.record_stream(st)
         front.wait_event(s.done)                                            # the slot's previous batch has left the tail
         qp, qs = queries.data_ptr(), queries.stride(0)
         if seed is None:
             seed = ix._hashing.next_seed()
         rc = L.nlsh_encode_hash(qp, self.Q, qs, *s.enc_pre, self._n_multi, seed, 0, *s.enc_post, front.cuda_stream)
+        pst = front
+        if self.plan is not None:
+            s.encoded.record(front)
+            pst = self.plan
+            pst.wait_event(s.encoded)
         if rc == 0:
-            rc = L.nlsh_scan_topk_cells_phase(*s.scan_pre, qp, qs, *s.scan_post, None, None, front.cuda_stream, _capi.PHASE_PLAN)
-        s.planned.record(front)
+            rc = L.nlsh_scan_topk_cells_phase(*s.scan_pre, qp, qs, *s.scan_post, None, None, pst.cuda_stream, _capi.PHASE_PLAN)
+        s.planned.record(pst)
         mid.wait_event(s.planned)
         if rc == 0:
             rc = L.nlsh_scan_topk_cells_phase(*s.scan_pre, qp, qs, *s.scan_post, events[0].cuda_event if events else None,

@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--q", type=int, default=10_000)
     ap.add_argument("--shard", default="buckets", choices=["buckets", "rows"])
     ap.add_argument("--pipeline", action="store_true", help="three-stage pipeline over three streams (nlsh_amd/pipeline.py)")
+    ap.add_argument("--split-front", default="auto", choices=["auto", "on", "off"], help="with --pipeline: the PLAN phase on a stream of its own (four stages); auto = the pipeline's own choice")
+    ap.add_argument("--depth", type=int, default=3)
     args = ap.parse_args()
     from nlsh_amd import io, synth
     from nlsh_amd.data import SIFT
@@ -61,7 +63,7 @@ def main():
     pipe = None
     if args.pipeline:
         from nlsh_amd.pipeline import QueryPipeline
-        pipe = QueryPipeline(indexer, queries, k=10, hash_times=10, depth=3, want_keys=True)
+        pipe = QueryPipeline(indexer, queries, k=10, hash_times=10, depth=args.depth, want_keys=True, split_front={"auto": None, "on": True, "off": False}[args.split_front])
         for i in range(3):
             pipe.submit(queries, seed=50 + i)
         torch.cuda.synchronize()
@@ -74,7 +76,7 @@ def main():
     enqueue_ms = 1e3 * (time.perf_counter() - t0) / args.steps      # host time to enqueue a step (the GPU runs behind)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    print(json.dumps({"world": args.world, "rank": args.rank, "shard": args.shard, "pipeline": bool(args.pipeline), "rows": hi - lo, "algo": indexer.last_algo,
+    print(json.dumps({"world": args.world, "rank": args.rank, "shard": args.shard, "pipeline": bool(args.pipeline), "split_front": (pipe.split_front if pipe is not None else None), "depth": args.depth, "rows": hi - lo, "algo": indexer.last_algo,
                       "local_step_ms": 1e3 * el / args.steps, "host_enqueue_ms": enqueue_ms, "scan_ms": float(np.mean([a.elapsed_time(b) for a, b in ev]))}))
 
 
