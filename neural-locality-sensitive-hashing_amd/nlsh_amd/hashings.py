@@ -122,9 +122,18 @@ class MultivariateBernoulli:
         return [stack[0][0].shape[1]] + [w.shape[0] for w, _ in stack]
 
     def _weights_signature(self):
+        """(storage address, version counter) of every parameter and buffer of the hasher: changes whenever an optimiser step, a
+        `load_state_dict`, a `.cuda()` or a reassigned parameter changes what the packed blob was built from.  Called on every hashing
+        call, so it walks a cached list of the modules' own `_parameters` / `_buffers` dicts (a reassigned tensor is seen through the
+        dict) instead of `module.parameters()` -- the recursive module walk cost 30 us per call, a third of the host time of a pipelined
+        batch (r04, cProfile of `QueryPipeline.submit`).  Submodules ADDED after the first call are not seen: rebuild the hashing."""
+        slots = self.__dict__.get("_sig_slots")
+        if slots is None:
+            slots = self._sig_slots = [(d, name) for m in self._hasher.modules() for d in (m._parameters, m._buffers) for name in d]
         sig = []
-        for p in itertools.chain(self._hasher.parameters(), self._hasher.buffers()):
-            sig.append((p.data_ptr(), p._version))
+        for d, name in slots:
+            t = d.get(name)
+            sig.append(None if t is None else (t.data_ptr(), t._version))
         return tuple(sig)
 
     def packed_weights(self):

@@ -37,6 +37,24 @@ class _Slot:
     pass
 
 
+_hip = None
+
+
+def _hip_runtime():
+    """hipEventRecord / hipStreamWaitEvent on raw handles: a pipelined batch records and waits on ten events, and through
+    torch.cuda.Event each costs 3.5-4 us of host time (r04 cProfile: 37 of the ~90 us it takes to enqueue a batch, which at eight
+    shards is what bounds the step); the same two HIP calls through ctypes cost ~1 us."""
+    global _hip
+    if _hip is None:
+        import ctypes
+        _hip = ctypes.CDLL("libamdhip64.so")
+        _hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        _hip.hipEventRecord.restype = ctypes.c_int
+        _hip.hipStreamWaitEvent.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
+        _hip.hipStreamWaitEvent.restype = ctypes.c_int
+    return _hip
+
+
 class QueryPipeline:
 
     def __init__(self, indexer, sample_queries, k=10, hash_times=10, depth=3, want_keys=False,
@@ -99,7 +117,9 @@ class QueryPipeline:
             s.status = torch.zeros((2,), dtype=torch.int32, device=dev)
             s.ws = torch.zeros((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)   # PLAN-phase head must start out zero (include/nlsh_hip.h)
             s.planned, s.scanned, s.done, s.encoded = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
-            s.done.record(torch.cuda.current_stream(dev))
+            for e in (s.planned, s.scanned, s.encoded, s.done):      # instantiate the hipEvent handles (torch creates them at the first record)
+                e.record(torch.cuda.current_stream(dev))
+            s.h_planned, s.h_scanned, s.h_encoded, s.h_done = s.planned.cuda_event, s.scanned.cuda_event, s.encoded.cuda_event, s.done.cuda_event
             # everything about the slot's launches that does not change from batch to batch, as plain ints: a submit is
             # four ctypes transitions + six event calls (built per call it cost 125 us of host time per batch, which
             # is what bounded the pipeline on small shards)
@@ -108,6 +128,7 @@ class QueryPipeline:
             self.slots.append(s)
         self._bind_weights()
         self._lib = _capi.lib()
+        self._hip = _hip_runtime()
         self._n_multi = indexer._n_multi_rows(self.Q)
         self.n_submitted = 0
         self.last_slot = None
@@ -146,33 +167,34 @@ class QueryPipeline:
         front.wait_stream(torch.cuda.current_stream(queries.device))        # the batch may still be in flight there
         for st in (front, mid, tail) + ((self.plan,) if self.plan is not None else ()):   # every stage reads the batch tensor
             queries.record_stream(st)
-        front.wait_event(s.done)                                            # the slot's previous batch has left the tail
+        hip, hf, hm, ht = self._hip, front.cuda_stream, mid.cuda_stream, tail.cuda_stream
+        rc_ev = hip.hipStreamWaitEvent(hf, s.h_done, 0)                     # the slot's previous batch has left the tail
         qp, qs = queries.data_ptr(), queries.stride(0)
         if seed is None:
             seed = ix._hashing.next_seed()
         rc = L.nlsh_encode_hash(qp, self.Q, qs, *s.enc_pre, self._n_multi, seed, 0, *s.enc_post, front.cuda_stream)
-        pst = front
+        hp = hf
         if self.plan is not None:
-            s.encoded.record(front)
-            pst = self.plan
-            pst.wait_event(s.encoded)
+            hp = self.plan.cuda_stream
+            rc_ev |= hip.hipEventRecord(s.h_encoded, hf) | hip.hipStreamWaitEvent(hp, s.h_encoded, 0)
         if rc == 0:
-            rc = L.nlsh_scan_topk_cells_phase(*s.scan_pre, qp, qs, *s.scan_post, None, None, pst.cuda_stream, _capi.PHASE_PLAN)
-        s.planned.record(pst)
-        mid.wait_event(s.planned)
+            rc = L.nlsh_scan_topk_cells_phase(*s.scan_pre, qp, qs, *s.scan_post, None, None, hp, _capi.PHASE_PLAN)
+        rc_ev |= hip.hipEventRecord(s.h_planned, hp) | hip.hipStreamWaitEvent(hm, s.h_planned, 0)
         if rc == 0:
             rc = L.nlsh_scan_topk_cells_phase(*s.scan_pre, qp, qs, *s.scan_post, events[0].cuda_event if events else None,
-                                        events[1].cuda_event if events else None, mid.cuda_stream, _capi.PHASE_SCAN)
-        s.scanned.record(mid)
-        tail.wait_event(s.scanned)
+                                        events[1].cuda_event if events else None, hm, _capi.PHASE_SCAN)
+        rc_ev |= hip.hipEventRecord(s.h_scanned, hm) | hip.hipStreamWaitEvent(ht, s.h_scanned, 0)
         if rc == 0:
-            rc = L.nlsh_scan_topk_cells_phase(*s.scan_pre, qp, qs, *s.scan_post, None, None, tail.cuda_stream, _capi.PHASE_MERGE)
+            rc = L.nlsh_scan_topk_cells_phase(*s.scan_pre, qp, qs, *s.scan_post, None, None, ht, _capi.PHASE_MERGE)
         _capi.check(rc)
+        if rc_ev:
+            raise _capi.NlshHipError(_capi.E_HIP, f"hipEventRecord / hipStreamWaitEvent failed ({rc_ev})")
         out = (s.out_dist, s.out_idx, s.ncand, s.out_keys)
         if self.exchange is not None:
             with torch.cuda.stream(tail):
                 out = tuple(self.exchange(s.out_keys, s.ncand)) + (None,)
-        s.done.record(tail)
+        if hip.hipEventRecord(s.h_done, ht):
+            raise _capi.NlshHipError(_capi.E_HIP, "hipEventRecord failed")
         self.last_slot = s
         return out
 
