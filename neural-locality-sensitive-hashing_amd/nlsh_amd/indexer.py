@@ -569,9 +569,8 @@ class Indexer:
     # the next FULL collection, like any long-lived object.  Because the counters restart from zero at every call, a tight
     # query loop would never reach the collector's thresholds for the older generations on its own: every
     # `_FULL_COLLECT_EVERY`-th promotion is followed by an explicit full collection (tens of ms in a torch process, so rare).
-    # It rewrites the host application's collector generations, so it is OPT-IN (`Indexer.promote_results = True`; bench.py
-    # turns it on and says so in its JSON line, and reports the protocol number without it beside it): by default the
-    # conversion only pauses the collector for its own duration.  Even when on it is skipped when the application holds
+    # It rewrites the host application's collector generations, so it is OPT-IN (`Indexer.promote_results = True`; bench.py never
+    # turns it on): by default the conversion only pauses the collector for its own duration.  Even when on it is skipped when the application holds
     # frozen objects of its own (gc.get_freeze_count() > 0) or has the collector disabled.
     promote_results = False
     # A caller that loops `ids, counts = indexer.query(batch)` frees the previous call's 10^4 lists when it rebinds the names: ~0.3 ms
@@ -579,8 +578,8 @@ class Indexer:
     # the indexer keeps a reference to its last TWO results and drops the older one right after the NEXT call has queued its device
     # work -- the deallocation then runs under the scan instead of in front of it.  Results are unchanged and stay the caller's to keep;
     # the cost is that up to two extra result sets (a few MB of Python objects each) stay alive per indexer.  Off by default for the
-    # same reason as `promote_results`: a library call should not change object lifetimes unasked.  bench.py turns both on for its
-    # headline region, says so, and reports the region with both off beside it.
+    # same reason as `promote_results`: a library call should not change object lifetimes unasked.  bench.py's headline `value` is
+    # measured with all of these off (r04); `protocol_qps_opt_in` is the same region with this switch and `untracked_results` on.
     defer_result_release = False
     # OPT-IN: hand the inner result lists out untracked by the cyclic collector (csrc/fastlists.c).  A row of ints cannot be part of a
     # cycle and 10^4 tracked young lists per call make the collector's next young pass cost ~0.26 ms -- but CPython never untracks
