@@ -17,7 +17,7 @@
 //   bscan    thread/bucket: block scan + one atomic per block -> disjoint pair/task ranges;
 //            task = (group of <= QB pairs, segment of <= seg rows), segment-major ids
 //   bscatter thread/(query,probe): claim a slot in the bucket's query list
-//   bprep    (tiled, cosine or d % 4 != 0 only) padded / pre-normalised copy of the queries
+//            (tiled, cosine / folded L2 / d % 4 != 0 only: extra workgroups of the same launch write the padded / pre-normalised query copy)
 //   bscan2 | bscan3: partial top-k per (task, query)
 //   bmerge   wave/query: merge the partial lists of its (probe, segment) pairs -> final top-k
 // Results do not depend on slot/task order: every list is merged with the (distance, id) comparator.
@@ -127,17 +127,43 @@ struct BArgs {
     int32_t *hits;             // [blocks of bplan] (query, probe) pairs each bplan block found a bucket for
     unsigned long long *tauq;  // [Q] running upper bound of each query's k-th best key (atomicMin), KEY_NONE-initialised
     const float *qpad;  // tiled variant: queries padded to d4p*4 floats (L2: pad = -eps; cosine: pre-normalised, pad = 0)
-    float *qpad_w;      // same buffer, writable (bprep); qpad aliases `queries` when no padding/normalisation is needed
+    float *qpad_w;      // same buffer, writable (prep_query); qpad aliases `queries` when no padding/normalisation is needed
     long long qpad_stride;
     int d4p;
 };
 
+// Padded / pre-normalised copy of one query for the tiled schedule (one wavefront per query): L2 pads with -eps ((q - 0) + eps == 0 on
+// padding), the folded L2 form stores q + eps, cosine stores x1 / max(||x1||, 1e-8) as cosine_similarity does.  Runs as extra
+// workgroups of bplan_kernel (r04: its own launch cost the cosine / folded / d % 4 != 0 configurations ~5 us per batch for 1 us of work).
+__device__ __forceinline__ void prep_query(const BArgs &a, int metric, long long q, int lane) {
+    const float *qp = a.queries + q * a.q_stride;
+    float *dst = a.qpad_w + q * a.qpad_stride;
+    const int n = a.d4p * 4;
+    if (metric == NLSH_METRIC_L2_EPS) {
+        for (int e = lane; e < n; e += 64) dst[e] = e < a.d ? qp[e] : -1e-6f;  // (q - 0) + eps == 0 on padding
+    } else if (metric == NLSH_METRIC_L2_EPS_FOLDED) {
+        for (int e = lane; e < n; e += 64) dst[e] = e < a.d ? qp[e] + 1e-6f : 0.0f;   // eps folded into the query: (q + eps) - c; 0 - 0 on padding
+    } else {
+        float ss = 0.0f;
+        for (int e = lane; e < a.d; e += 64) ss = fmaf(qp[e], qp[e], ss);
+        for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
+        const float nrm = fmaxf(sqrtf(ss), 1e-8f);  // x1 / max(||x1||, eps), as cosine_similarity does
+        for (int e = lane; e < n; e += 64) dst[e] = e < a.d ? qp[e] / nrm : 0.0f;
+    }
+}
+
 // Bucket lookup of every (query, probe): binary search of the key in uniq[nb].  The first ~10 of its ~13 steps run on a
 // coarse table in LDS (every `stride`-th key, <= 1024 entries, loaded once per workgroup), the last log2(stride) on the
 // stride-long run in global memory: 3-4 dependent global loads per thread instead of 13.
-__global__ __launch_bounds__(256) void bplan_kernel(BArgs a, int stride) {
+// Workgroups past `plan_blocks` prepare the tiled schedule's query copy instead (prep_metric >= 0), four queries each.
+__global__ __launch_bounds__(256) void bplan_kernel(BArgs a, int stride, unsigned plan_blocks, int prep_metric) {
     __shared__ int32_t coarse[1024];
     __shared__ int whits[4];
+    if (blockIdx.x >= plan_blocks) {   // uniform per workgroup: no barrier below is reached by these
+        const long long q = (long long)(blockIdx.x - plan_blocks) * 4 + (threadIdx.x >> 6);
+        if (q < a.Q) prep_query(a, prep_metric, q, threadIdx.x & 63);
+        return;
+    }
     const int nco = (a.nb + stride - 1) / stride;
     for (int i = threadIdx.x; i < nco; i += 256) coarse[i] = a.uniq[(long long)i * stride];
     __syncthreads();
@@ -482,7 +508,7 @@ __global__ __launch_bounds__(256) void bscan2_kernel(BArgs a) {
 // global loads -> ds_write_b128, odd row stride = conflict-free column reads) and every lane OWNS ONE ROW of
 // each 64-row tile: it walks the row in k order and updates QW query accumulators per tile, the query values
 // arriving as wave-uniform scalar loads (s_load from the queries, or from a padded / pre-normalised copy when
-// bprep is needed).  No cross-lane reduction at all: 3 VALU per element and query for L2 ((q-c), +eps, fma),
+// the prepared query copy is needed).  No cross-lane reduction at all: 3 VALU per element and query for L2 ((q-c), +eps, fma),
 // 1 for cosine; the distance of lane l's row is a k-ascending fmaf chain, bit-identical to the oracle's scalar
 // loop.  Four waves share the tile, so a row is fetched from HBM/L2 once per 16 queries.  The next k-block's
 // global loads are issued before the current one is computed (load early, ds_write late).
@@ -500,25 +526,6 @@ __global__ __launch_bounds__(256) void bscan2_kernel(BArgs a) {
 // next 64-byte query line with a dummy scalar load one line ahead (SGPR spills 28 -> 50: 0.355 vs 0.331 ms); one
 // s_load_dwordx16 per query line instead of four x4 (64 VGPRs kept, +-0: the scalar loads are not what waves wait for).
 typedef const __attribute__((address_space(4))) float *const_f32p;
-
-__global__ __launch_bounds__(64) void bprep_kernel(BArgs a, int metric) {
-    const long long q = blockIdx.x;
-    const int lane = threadIdx.x;
-    const float *qp = a.queries + q * a.q_stride;
-    float *dst = a.qpad_w + q * a.qpad_stride;
-    const int n = a.d4p * 4;
-    if (metric == NLSH_METRIC_L2_EPS) {
-        for (int e = lane; e < n; e += 64) dst[e] = e < a.d ? qp[e] : -1e-6f;  // (q - 0) + eps == 0 on padding
-    } else if (metric == NLSH_METRIC_L2_EPS_FOLDED) {
-        for (int e = lane; e < n; e += 64) dst[e] = e < a.d ? qp[e] + 1e-6f : 0.0f;   // eps folded into the query: (q + eps) - c; 0 - 0 on padding
-    } else {
-        float ss = 0.0f;
-        for (int e = lane; e < a.d; e += 64) ss = fmaf(qp[e], qp[e], ss);
-        for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
-        const float nrm = fmaxf(sqrtf(ss), 1e-8f);  // x1 / max(||x1||, eps), as cosine_similarity does
-        for (int e = lane; e < n; e += 64) dst[e] = e < a.d ? qp[e] / nrm : 0.0f;
-    }
-}
 
 template <int QW>
 struct QChunk { float v[QW][4]; };  // wave-uniform: lives in SGPRs
@@ -544,7 +551,7 @@ __device__ __forceinline__ void apply_qchunk(const QChunk<QW> &qc, const float4 
                 const float t0 = (q0 - rv.x) + 1e-6f, t1 = (q1 - rv.y) + 1e-6f, t2 = (q2 - rv.z) + 1e-6f, t3 = (q3 - rv.w) + 1e-6f;
                 acc[jq] = fmaf(t3, t3, fmaf(t2, t2, fmaf(t1, t1, fmaf(t0, t0, acc[jq]))));
             } else if (METRIC == NLSH_METRIC_L2_EPS_FOLDED) {
-                const float t0 = q0 - rv.x, t1 = q1 - rv.y, t2 = q2 - rv.z, t3 = q3 - rv.w;   // q already carries + eps (bprep)
+                const float t0 = q0 - rv.x, t1 = q1 - rv.y, t2 = q2 - rv.z, t3 = q3 - rv.w;   // q already carries + eps (prep_query)
                 acc[jq] = fmaf(t3, t3, fmaf(t2, t2, fmaf(t1, t1, fmaf(t0, t0, acc[jq]))));
             } else {
                 acc[jq] = fmaf(q3, rv.w, fmaf(q2, rv.z, fmaf(q1, rv.y, fmaf(q0, rv.x, acc[jq]))));
@@ -641,7 +648,7 @@ __device__ __forceinline__ void load_qset(QSet &q, const const_f32p (&qk)[4], in
     "v_add_f32 %[t2], 0x358637bd, %[t2]\n\tv_add_f32 %[t3], 0x358637bd, %[t3]\n\t"                                   \
     "v_fmac_f32 %[a" #J "], %[t0], %[t0]\n\tv_fmac_f32 %[a" #J "], %[t1], %[t1]\n\t"                                 \
     "v_fmac_f32 %[a" #J "], %[t2], %[t2]\n\tv_fmac_f32 %[a" #J "], %[t3], %[t3]\n\t"
-// The 2-op form (NLSH_METRIC_L2_EPS_FOLDED): eps is folded into the query copy bprep writes, a block is v_sub + v_fmac -- 8
+// The 2-op form (NLSH_METRIC_L2_EPS_FOLDED): eps is folded into the query copy prep_query writes, a block is v_sub + v_fmac -- 8
 // instead of 12 VALU per chunk and query.  (q + eps) - c rounds differently from (q - c) + eps, so it is NOT the oracle's bits:
 // an opt-in within the north_star's 1e-4 tolerance, never the default.
 #define NLSH_QBLK2(J)                                                                                              \
@@ -1338,7 +1345,8 @@ int bucket_scan_run(const BucketScanCall &c) {
         // device-coherent sc1 accesses instead, against 35 us for the separate launches: crossing XCDs inside a kernel
         // costs as much as a kernel boundary on this part.)  The per-bucket pair counters need no clearing launch: the
         // scatter step hands every count back, so they are zero again after every call (workspace contract, nlsh_hip.h).
-        hipLaunchKernelGGL(bplan_kernel, dim3(gp), dim3(256), 0, s, a, stride);
+        const unsigned gprep = prep ? (unsigned)((c.Q + 3) / 4) : 0u;   // the query copy rides in the same launch
+        hipLaunchKernelGGL(bplan_kernel, dim3(gp + gprep), dim3(256), 0, s, a, stride, gp, prep ? metric : -1);
         // (r03: bcount + bscan as ONE single-workgroup launch for indexes of <= 8192 buckets -- strided bucket map, counts and prefixes
         // through 64 KB of LDS, all loads of a thread's 8 buckets issued together -- took 23 us against 16.4 us for the two launches
         // below (33 us before the loads were batched): one CU writes 12 k task descriptors slower than 23 workgroups do.)
@@ -1348,7 +1356,6 @@ int bucket_scan_run(const BucketScanCall &c) {
             hipLaunchKernelGGL(bscan_kernel, dim3(gb), dim3(256), 0, s, a, (int)gp);
         }
         hipLaunchKernelGGL(bscatter_kernel, dim3(gp), dim3(256), 0, s, a);
-        if (prep) hipLaunchKernelGGL(bprep_kernel, dim3((unsigned)c.Q), dim3(64), 0, s, a, metric);
     }
     if ((c.phases & NLSH_PHASE_SCAN) && c.max_tasks > 0) {
         if (c.ev_begin) NLSH_CHECK_HIP(hipEventRecord((hipEvent_t)c.ev_begin, s));
