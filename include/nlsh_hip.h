@@ -71,7 +71,8 @@ const char *nlsh_last_error(void);
  * does, without leaving the device.
  * ------------------------------------------------------------------------------------------- */
 
-/* Number of floats of the packed (MFMA-fragment-ordered) weight blob for a layer stack.
+/* Number of floats of the packed (MFMA-fragment-ordered) weight blob for a layer stack: every layer in the fragment order of the
+ * 32-row-tile forms, then the hidden layers once more in 16x16x4 order (the 16-row form batches of <= 4096 rows take).
  * dims [host] = {d_in, h_1, ..., H}, n_layers = number of Linear layers (len(dims) - 1). */
 int64_t nlsh_encoder_packed_floats(int n_layers, const int *dims);
 

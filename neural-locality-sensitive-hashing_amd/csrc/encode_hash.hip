@@ -5,6 +5,8 @@
 // .cpu().numpy() -> nlsh/utils.pyx:6-32 (binarr_to_int, set()).  Nothing leaves the device.
 //
 // gfx950 mapping
+//   * three forms, same arithmetic: index builds 128 rows per workgroup, query batches 32, batches of <= 4096 rows 16 (H16, all
+//     layers as 16x16x4 tiles); described here for the 32-row-tile forms:
 //   * one workgroup (NW = 8 wavefronts, 512 threads) owns M = 32*RT rows; their activations never
 //     leave LDS (two ping-pong [M][S] fp32 images, 133 KB at width 256, so ONE workgroup per CU: the
 //     two wavefronts per SIMD are what overlaps one wave's LDS/L2 waits, write-back and epilogue VALU
@@ -31,6 +33,7 @@ struct LayerDesc {
     int K, N;      // logical in/out width
     int Kp, Np;    // padded: Kp % 8 == 0, Np % 32 == 0
     long long w_off, b_off;  // float offsets into the packed blob
+    long long w16_off;       // the same weights packed for 16x16x4 tiles (hidden layers: a second copy behind the blob; output layer: == w_off)
 };
 
 struct EncArgs {
@@ -76,6 +79,11 @@ __device__ __forceinline__ void philox4x32_10(unsigned long long seed, uint32_t 
 #ifndef NLSH_ENC_SINGLE_MAX_ROWS
 #define NLSH_ENC_SINGLE_MAX_ROWS 16384
 #endif
+// Batches of at most this many rows take the 16-row form (H16): as long as its workgroups are at most one per CU (256 x 16 rows) it is
+// the shorter critical path (24.5 us against 27.2 for the 32-row form, 64 ... 4096 rows); beyond that it loses -- see the kernel.
+#ifndef NLSH_ENC_H16_MAX_ROWS
+#define NLSH_ENC_H16_MAX_ROWS 4096
+#endif
 
 // Diagnostic build only (make EXTRA=-DNLSH_ENC_TRACE, tools/enc_trace.py): thread 0 of every workgroup
 // leaves the 100 MHz wall_clock64 stamp of each phase boundary in the first floats of its z_out rows.
@@ -90,9 +98,17 @@ __device__ __forceinline__ void philox4x32_10(unsigned long long seed, uint32_t 
 // With RT = 1 that is 33 KB at width 256 -- small enough to sit on a CU BESIDE six resident workgroups of the scan
 // kernel (20 KB each), which is what lets the batch pipeline (nlsh_amd/pipeline.py) run a query batch's encode under
 // the previous batch's scan; the 133 KB ping-pong form only finds a CU once the scan's dispatch queue has drained.
-template <int RT, int NW, bool SINGLE, int MT = 1, int WPE = 1>  // MT: column tiles a wave may own in SINGLE mode (1: width <= 32*NW); WPE: waves per SIMD the registers must allow
+// H16 (r04): 16-row workgroups whose layers are ALL 16x16x4 tiles (MT = 16-column tiles a wave may own); same k-ascending fmaf
+// chains (guide, FP32-input MFMA), so z keeps its bits.  Built to balance the 10^4-query batch -- 313 32-row workgroups on 256 CUs:
+// the 57 CUs that host two of them take 42 us where one workgroup alone takes 28 (8192 rows 28.0 us, 8224 rows 40.9 us), and the
+// launch lasts as long as its busiest CU -- and measured the other way round there: every workgroup streams the whole 410 KB of
+// weights whatever its rows, a 16x16x4 tile needs twice the operand bytes per flop of a 32x32x2 one, and each further 16-row
+// workgroup on a CU adds 12.5 us (24.5 / 36.9 / 47.4 / 62.0 us at 1 / 2 / 3 / 4 per CU) where a second 32-row one adds 14 for twice
+// the rows.  It IS the shorter critical path while there is at most one workgroup per CU: batches of <= 4096 rows (24.5 vs 27.2 us).
+template <int RT, int NW, bool SINGLE, int MT = 1, int WPE = 1, bool H16 = false>  // MT: column tiles a wave may own in SINGLE mode (1: width <= 32*NW); WPE: waves per SIMD the registers must allow
 __global__ __launch_bounds__(NW * 64, WPE) void encode_hash_kernel(EncArgs a) {
-    constexpr int M = 32 * RT;
+    constexpr int M = H16 ? 16 : 32 * RT;
+    static_assert(!H16 || (SINGLE && RT == 1), "the 16-row form runs on a single LDS image");
     constexpr int NTH = NW * 64;
     extern __shared__ float4 smem4[];
     float *smem = reinterpret_cast<float *>(smem4);
@@ -161,7 +177,82 @@ __global__ __launch_bounds__(NW * 64, WPE) void encode_hash_kernel(EncArgs a) {
         const float4 *Wp = reinterpret_cast<const float4 *>(a.packed + L.w_off);
         const float *Bp = a.packed + L.b_off;
         const bool last = (l + 1 == a.n_layers);
-        if (!last) {
+        if (H16) {
+            // every layer as 16x16x4 tiles: the workgroup's ONE 16-row tile x (width / 16) column tiles, dealt over the waves (tile ct =
+            // wave + m * NW); a wave walks its tiles in LOCK STEP over k, so the four A values of a 16-k group are read from LDS once for
+            // all of them and their MFMA chains interleave.  Lane l holds A[row l & 15][k = l >> 4] and B[k = l >> 4][col l & 15].
+            typedef float f32x4v __attribute__((ext_vector_type(4)));
+            const int ct16 = last ? (a.H + 15) >> 4 : L.Np >> 4, ngr = (L.K + 15) >> 4;
+            const float4 *W16 = reinterpret_cast<const float4 *>(a.packed + L.w16_off);
+            const int g = lane >> 4, l16 = lane & 15;
+            const int pa = ((g & 1) << 2) + (g >> 1);   // pos(g) inside a chunk; pos(4 + g) = pa + 2
+            const float *arow = in + (size_t)l16 * S + pa;
+            constexpr int OR = 4;                        // B ring per tile: groups of 16 k in flight
+            f32x4v acc[MT];
+            float4 B[MT][OR];
+            const float4 *w0[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                acc[m] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+                const int ct = min(wave + m * NW, ct16 - 1);   // tiles past the layer's width redo its last one (valid addresses), results dropped
+                w0[m] = W16 + (size_t)ct * ngr * 64 + lane;
+#pragma unroll
+                for (int j = 0; j < OR; ++j) B[m][j] = w0[m][(size_t)min(j, ngr - 1) * 64];
+            }
+            if (wave < ct16) {
+                for (int j0 = 0; j0 < ngr; j0 += OR) {
+#pragma unroll
+                    for (int jj = 0; jj < OR; ++jj) {
+                        const int j = j0 + jj;
+                        if (j < ngr) {
+                            float4 bq[MT];
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) {
+                                bq[m] = B[m][jj];
+                                B[m][jj] = w0[m][(size_t)min(j + OR, ngr - 1) * 64];
+                            }
+                            const int c0 = 2 * j, c1 = 2 * j + 1;
+                            const float a0 = arow[c0 * 8], a1 = arow[c0 * 8 + 2];
+                            const bool two = c1 < nch;   // Kp is a multiple of 8, not of 16: the last group may hold one chunk only
+                            const float a2 = two ? arow[c1 * 8] : 0.0f, a3 = two ? arow[c1 * 8 + 2] : 0.0f;
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bq[m].x, acc[m], 0, 0, 0);
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bq[m].y, acc[m], 0, 0, 0);
+                            if (two) {
+#pragma unroll
+                                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bq[m].z, acc[m], 0, 0, 0);
+#pragma unroll
+                                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bq[m].w, acc[m], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();   // one image: every wave has finished reading this layer's input before it is overwritten
+            const int ncol_keep = last ? a.H : a.L[l + 1].Kp;   // columns the next layer reads (>= N, zero padded) / the H code bits
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int ct = wave + m * NW;
+                const int col = ct * 16 + l16;
+                if (ct < ct16 && col < (last ? 32 : ncol_keep)) {
+                    const float bias = Bp[col];
+                    if (last) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) out[(4 * g + i) * 33 + col] = acc[m][i] + bias;   // z, natural column order
+                    } else {
+                        const int pc = pos(col);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {   // bias + ReLU (encoders.py:19-20); C/D map: col = lane & 15, row = 4 * (lane >> 4) + i
+                            const float v = acc[m][i] + bias;
+                            out[(size_t)(4 * g + i) * S + pc] = v > 0.0f ? v : 0.0f;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            ENC_STAMP(2 + (l < 4 ? l : 4));
+        } else if (!last) {
             const int NT = L.Np >> 5;
             const int ncol_keep = a.L[l + 1].Kp;  // columns the next layer reads (>= N, zero padded)
             f32x16 accs[MT][RT];
@@ -480,6 +571,11 @@ static int fill_layers(int n_layers, const int *dims, LayerDesc *L, long long *t
         L[l].b_off = off;
         off += L[l].Np;
     }
+    for (int l = 0; l < n_layers; ++l) {   // the 16x16x4 packing of the hidden layers (the 16-row query-batch form), behind everything else
+        if (l + 1 == n_layers) { L[l].w16_off = L[l].w_off; continue; }
+        L[l].w16_off = off;
+        off += (long long)(L[l].Np / 16) * ((dims[l] + 15) / 16) * 256;
+    }
     *total = off;
     return 0;
 }
@@ -524,9 +620,13 @@ extern "C" int nlsh_encoder_pack(int n_layers, const int *dims, const float *con
         if (l + 1 == n_layers)
             hipLaunchKernelGGL(pack_out_weights_kernel, dim3(grid), dim3(256), 0, s, W[l], b[l], L[l].K, L[l].N, (L[l].K + 15) / 16,
                                (L[l].N + 15) / 16, L[l].Np, packed + L[l].w_off, packed + L[l].b_off);
-        else
+        else {
             hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, s, W[l], b[l], L[l].K, L[l].N, L[l].Kp, L[l].Np,
                                packed + L[l].w_off, packed + L[l].b_off);
+            // second copy for the 16-row form: Np / 16 column tiles (columns >= N zero), same bias vector
+            hipLaunchKernelGGL(pack_out_weights_kernel, dim3(grid), dim3(256), 0, s, W[l], b[l], L[l].K, L[l].N, (L[l].K + 15) / 16,
+                               L[l].Np / 16, L[l].Np, packed + L[l].w16_off, packed + L[l].b_off);
+        }
         NLSH_CHECK_HIP(hipGetLastError());
     }
     return NLSH_OK;
@@ -585,7 +685,12 @@ extern "C" int nlsh_encode_hash(const float *x, int64_t n, int64_t x_stride, int
         long long grid = (n + 31) / 32;
         int max_np = 0;  // widest hidden layer decides how many column tiles a wave owns
         for (int l = 0; l + 1 < n_layers; ++l) if (a.L[l].Np > max_np) max_np = a.L[l].Np;
-        if (max_np <= 32 * 8) {
+        if (n <= NLSH_ENC_H16_MAX_ROWS && max_np <= 16 * 8 * 2) {   // 16-row workgroups, every layer as 16x16x4 tiles (two column tiles per wave:
+            // 78 VGPRs, three workgroups per CU; wider encoders would need five tiles per wave = 175 VGPRs and stay on the 32-row form)
+            const size_t lds16 = (size_t)16 * a.S * 4;
+            NLSH_CHECK_HIP(hipFuncSetAttribute((const void *)encode_hash_kernel<1, 8, true, 2, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+            hipLaunchKernelGGL((encode_hash_kernel<1, 8, true, 2, 1, true>), dim3((unsigned)((n + 15) / 16)), dim3(512), lds16, s, a);
+        } else if (max_np <= 32 * 8) {
             NLSH_CHECK_HIP(hipFuncSetAttribute((const void *)encode_hash_kernel<1, 8, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL((encode_hash_kernel<1, 8, true, 1>), dim3((unsigned)grid), dim3(512), lds, s, a);
         } else {

@@ -73,7 +73,9 @@ def test_encode_hash_vs_oracle_and_reference(case):
         hashing.hash(dev(x), 0)                          # hashings.py:83
 
 
-@pytest.mark.parametrize("n_rows", [1, 63, 64, 65, 1000])
+# the three forms of the encoder: <= 4096 rows 16-row workgroups of 16x16x4 tiles, <= 16384 rows 32-row workgroups on one LDS image,
+# beyond that the 128-row index-build form -- every one the same k-ascending fmaf chain as the oracle, at and around the switch-overs
+@pytest.mark.parametrize("n_rows", [1, 15, 16, 17, 63, 64, 65, 1000, 4096, 4097, 5000, 16384, 16385, 20001])
 def test_encode_hash_ragged_sizes_bit_exact(n_rows):
     d, hidden, H = 128, (256, 256), 16
     Ws, bs = synth.make_weights([d] + list(hidden) + [H], seed=5)

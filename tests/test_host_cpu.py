@@ -25,7 +25,8 @@ def test_capi_library_exports_every_declared_symbol():
     assert lib.nlsh_abi_version() == 2
     # pure host-side argument validation (no device needed): errors come back as codes + message
     dims = _capi.int_array([128, 256, 256, 16])
-    assert lib.nlsh_encoder_packed_floats(3, dims) == 256 * 128 + 256 + 256 * 256 + 256 + 32 * 256 + 32
+    # the 32x32x2 fragments of every layer + biases, then (r04) the hidden layers once more packed for 16x16x4 tiles (the 16-row form)
+    assert lib.nlsh_encoder_packed_floats(3, dims) == (256 * 128 + 256 + 256 * 256 + 256 + 32 * 256 + 32) + (256 * 128 + 256 * 256)
     assert lib.nlsh_encoder_packed_floats(3, _capi.int_array([128, 256, 256, 33])) == -1
     assert b"hash_size" in lib.nlsh_last_error()
     assert lib.nlsh_encoder_packed_floats(2, _capi.int_array([128, 700, 16])) == -1       # 128 ok, 700 too wide
