@@ -90,6 +90,13 @@ def parse(argv=None):
                     help="sift1m only.  manifold: synth.sift_manifold (6-d latent manifold: nearest neighbours are meaningful, what the "
                          "learned hash is trained on; headline).  clusters: SURVEY 8(d)'s own generator, synth.sift_like (1,000 isotropic "
                          "Gaussian clusters, sigma 24), with the hash trained on it (checkpoints/sift1m_clusters_h16.npz)")
+    ap.add_argument("--dataset", default=None,
+                    help="REAL data instead of the seeded generators: an ann-benchmarks HDF5 file (needs h5py) or a TEXMEX directory "
+                         "(*base.fvecs|bvecs, *query.fvecs, *groundtruth.ivecs), read by nlsh_amd.data.SIFT / Glove (--workload picks the class "
+                         "and metric); corpus = `train`, one query batch = the first --queries rows of `test`, recall against the file's own "
+                         "`neighbors`.  `data` then reads \"real\".  Pair with --hash-checkpoint (else a random-init hash)")
+    ap.add_argument("--hash-checkpoint", default=None, help="hasher weights for --dataset: our .npz, a state dict, or the reference's TorchScript _cpu.pt (nlsh/hashings.py:53-57)")
+    ap.add_argument("--unit-norm", action="store_true", help="--dataset: standardise with the training set's mean / std like SIFT(unit_norm=True) (nlsh/data.py:125-129)")
     ap.add_argument("--rows", "--n", dest="n", type=int, default=int(os.environ.get("NLSH_BENCH_N", 0)))
     ap.add_argument("--queries", "--q", dest="q", type=int, default=int(os.environ.get("NLSH_BENCH_Q", 10_000)))
     ap.add_argument("--batches", type=int, default=4, help="distinct query batches the timed steps rotate over")
@@ -193,32 +200,61 @@ def main():
     if args.workload == "sift1m" and args.data == "clusters":
         wl = dict(wl, ckpt="sift1m_clusters_h16.npz", cfg="configs[1]: SIFT1M-shaped (SURVEY 8(d) generator: synthetic SIFT-like integers, "
                   "1,000 isotropic Gaussian clusters, sigma 24, synth.sift_like, standardised)")
-    N, d, H = args.n or wl["N"], args.dim or wl["d"], args.hash_size or wl["H"]
-    args.hash_size_eff = H
-    Q, k, P, metric, B = args.q, args.k, args.hash_times, wl["metric"], max(1, args.batches)
-    if args.workload == "sift1m":
-        gen = synth.sift_manifold if args.data == "manifold" else synth.sift_like
-        corpus_h, mean, std = synth.standardise(gen(N, d, seed=synth.SEED_DATA))
-        batches_h = [synth.standardise(gen(Q, d, seed=synth.SEED_QUERY + 17 * i), mean, std)[0] for i in range(B)]
+    gt_file = None
+    if args.dataset:
+        # real files: the dataset classes of the facade read them exactly like the reference's (nlsh/data.py:14-46,112-140)
+        from nlsh_amd import io as nio
+        ds = (SIFT if wl["metric"] == "l2" else Glove)(args.dataset, unit_norm=args.unit_norm)
+        ds.load()
+        corpus_h = np.ascontiguousarray(ds.training[: args.n] if args.n else ds.training, dtype=np.float32)
+        N, d = corpus_h.shape
+        Q = min(args.q, ds.testing.shape[0])
+        batches_h = [np.ascontiguousarray(ds.testing[:Q], dtype=np.float32)]
+        gt_file = np.asarray(ds.ground_truth)[:Q]
+        if args.n and gt_file.max() >= N:
+            gt_file = None                      # a truncated corpus has other neighbours: brute force below instead
+        wl = dict(wl, cfg=f"REAL data {os.path.basename(os.path.normpath(args.dataset))} ({ds.__class__.__name__}, unit_norm={args.unit_norm})")
+        if args.hash_checkpoint:
+            Ws, bs = nio.load_hasher_weights(args.hash_checkpoint)
+            H = int(Ws[-1].shape[0])
+            hidden = [int(w.shape[0]) for w in Ws[:-1]]
+            hash_desc = f"learned: {args.hash_checkpoint}, {d}->{'->'.join(map(str, hidden))}->{H}"
+        else:
+            H = args.hash_size or wl["H"]
+            hidden = [256, 256]
+            Ws, bs = synth.make_weights([d] + hidden + [H], seed=synth.SEED_WEIGHTS)
+            hash_desc = f"seeded nn.Linear-default init {d}->256->256->{H} (random-init hash)"
+        args.hash_size_eff = H
+        k, P, metric, B = args.k, args.hash_times, wl["metric"], 1
     else:
-        corpus_h = synth.glove_manifold(N, d, seed=synth.SEED_DATA)
-        batches_h = [synth.glove_manifold(Q, d, seed=synth.SEED_QUERY + 17 * i) for i in range(B)]
-    ckpt = os.path.join(ROOT, "neural-locality-sensitive-hashing_amd", "checkpoints", wl["ckpt"])
-    if d == wl["d"] and H == wl["H"] and os.path.exists(ckpt) and not args.random_init:
-        arrs = np.load(ckpt)
-        Ws, bs = [arrs[f"W{i}"] for i in range(3)], [arrs[f"b{i}"] for i in range(3)]
-        hash_desc = (f"learned: triplet loss (margin 1.0, random negatives, 5000 Adam steps, tools/train_hash.py) on this "
-                     f"synthetic corpus, {d}->256->256->{H}, checkpoints/{wl['ckpt']}")
-    else:
-        Ws, bs = synth.make_weights([d, 256, 256, H], seed=synth.SEED_WEIGHTS)
-        hash_desc = f"seeded nn.Linear-default init {d}->256->256->{H} (random-init hash)"
+        hidden = [256, 256]
+        N, d, H = args.n or wl["N"], args.dim or wl["d"], args.hash_size or wl["H"]
+        args.hash_size_eff = H
+        Q, k, P, metric, B = args.q, args.k, args.hash_times, wl["metric"], max(1, args.batches)
+        if args.workload == "sift1m":
+            gen = synth.sift_manifold if args.data == "manifold" else synth.sift_like
+            corpus_h, mean, std = synth.standardise(gen(N, d, seed=synth.SEED_DATA))
+            batches_h = [synth.standardise(gen(Q, d, seed=synth.SEED_QUERY + 17 * i), mean, std)[0] for i in range(B)]
+        else:
+            corpus_h = synth.glove_manifold(N, d, seed=synth.SEED_DATA)
+            batches_h = [synth.glove_manifold(Q, d, seed=synth.SEED_QUERY + 17 * i) for i in range(B)]
+        ckpt = os.path.join(ROOT, "neural-locality-sensitive-hashing_amd", "checkpoints", wl["ckpt"])
+        if d == wl["d"] and H == wl["H"] and os.path.exists(ckpt) and not args.random_init:
+            arrs = np.load(ckpt)
+            Ws, bs = [arrs[f"W{i}"] for i in range(3)], [arrs[f"b{i}"] for i in range(3)]
+            hash_desc = (f"learned: triplet loss (margin 1.0, random negatives, 5000 Adam steps, tools/train_hash.py) on this "
+                         f"synthetic corpus, {d}->256->256->{H}, checkpoints/{wl['ckpt']}")
+        else:
+            Ws, bs = synth.make_weights([d, 256, 256, H], seed=synth.SEED_WEIGHTS)
+            hash_desc = f"seeded nn.Linear-default init {d}->256->256->{H} (random-init hash)"
     # keys wrap to int16 like the reference (nlsh/utils.pyx:7-15) up to 16 bits; wider hashes use the full code
-    hashing = MultivariateBernoulli(MultiLayerRelu(d, [256, 256]), H, None, compat=H <= 16)
+    hashing = MultivariateBernoulli(MultiLayerRelu(d, hidden, with_bias=bs[0] is not None), H, None, compat=H <= 16)
     lin = [m for m in hashing._hasher.modules() if isinstance(m, torch.nn.Linear)]
     with torch.no_grad():
         for m, W, b in zip(lin, Ws, bs):
-            m.weight.copy_(torch.from_numpy(W))
-            m.bias.copy_(torch.from_numpy(b))
+            m.weight.copy_(torch.from_numpy(np.asarray(W, dtype=np.float32)))
+            if b is not None:
+                m.bias.copy_(torch.from_numpy(np.asarray(b, dtype=np.float32)))
     hashing.train_mode(False)
 
     lo, hi = shard_range(N, rank, world)
@@ -436,7 +472,8 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         enc_ms = e0.elapsed_time(e1) / 5
-        flops = 2.0 * (d * 256 + 256 * 256 + 256 * H) * shard.shape[0]
+        dims_ = [d] + list(hidden) + [H]
+        flops = 2.0 * sum(a_ * b_ for a_, b_ in zip(dims_[:-1], dims_[1:])) * shard.shape[0]
         enc = {"kernel": "encode_hash_kernel (fp32 MFMA 32x32x2, fused bits + keys)", "rows": int(shard.shape[0]), "ms": enc_ms,
                "tflops": flops / (enc_ms * 1e-3) / 1e12, "peak_tflops": MFMA_F32_PEAK_TFLOPS,
                "mfma_util": flops / (enc_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}
@@ -468,9 +505,12 @@ def main():
 
     result = None
     if rank == 0:
-        corpus_d = torch.from_numpy(corpus_h).to(dev)
-        gt = brute_force_topk(qb[0], corpus_d, k, metric).cpu().numpy()
-        del corpus_d
+        if gt_file is not None and gt_file.shape[1] >= k:
+            gt = gt_file[:, :k]                  # the dataset's own `neighbors` (nlsh/trainers/base.py:42: ground_truth[:, :K])
+        else:
+            corpus_d = torch.from_numpy(corpus_h).to(dev)
+            gt = brute_force_topk(qb[0], corpus_d, k, metric).cpu().numpy()
+            del corpus_d
     # untimed: all lists on every rank (rank 0 computes the recall from them)
     # every rank takes part in the (collective) protocol call the recall is computed from; ONE fixed probe seed at every N,
     # so recall@10 and the candidate counts are the same numbers at 1, 2, 4 and 8 GPUs
@@ -524,7 +564,7 @@ def main():
                       "queries/sec + recall@10 (GloVe-1.2M 100-d cosine 24-bit: BASELINE.json configs[2], not the headline)",
             "value": value, "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "real" if args.dataset else "synthetic",
             "recall_at_10": recall,
             "value_protocol": "Indexer.query(batch, k, hash_times) -> Python lists of ALL Q queries on the calling rank, K synchronous calls "
                               "(nlsh/trainers/base.py:93-96), the facade's DEFAULT settings: what an unmodified Trainer.fit gets.  protocol_qps_opt_in is the same "

@@ -351,3 +351,40 @@ def test_indexer_hashes_a_batchnorm_encoder_in_train_mode_batch_by_batch_like_th
     with pytest.raises(_capi.NlshHipError):
         pipe.submit(x[:128].contiguous())
     hashing.train_mode(False)
+
+
+def test_bench_runs_on_real_files_given_as_a_texmex_directory(tmp_path):
+    """the day real SIFT1M / GloVe files are supplied, `bench.py --dataset PATH --hash-checkpoint CKPT` reads them through
+    the facade's dataset classes (nlsh/data.py:14-46,112-140) and scores recall against the file's own `neighbors`.  Here: a TEXMEX
+    directory written from seeded data with exact ground truth, a checkpoint in the reference's parameter naming."""
+    import json
+    import subprocess
+    import sys
+    from nlsh_amd import io
+    from nlsh_amd.data import brute_force_topk
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(11)
+    N, Q, d, H = 20000, 700, 32, 10
+    base = rng.standard_normal((N, d)).astype(np.float32)
+    query = (base[rng.integers(0, N, Q)] + 0.05 * rng.standard_normal((Q, d))).astype(np.float32)
+    gt = brute_force_topk(dev(query), dev(base), 100, "l2").cpu().numpy().astype(np.int32)
+    root = tmp_path / "toy"
+    root.mkdir()
+    io.write_vecs(str(root / "toy_base.fvecs"), base)
+    io.write_vecs(str(root / "toy_query.fvecs"), query)
+    io.write_vecs(str(root / "toy_groundtruth.ivecs"), gt)
+    Ws, bs = synth.make_weights([d, 48, H], seed=4)
+    np.savez(tmp_path / "hash.npz", **{f"W{i}": w for i, w in enumerate(Ws)}, **{f"b{i}": b for i, b in enumerate(bs)})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dataset", str(root), "--hash-checkpoint", str(tmp_path / "hash.npz"),
+                          "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["data"] == "real" and "toy" in rec["config"]["workload"] and "hash.npz" in rec["config"]["hash"]
+    assert rec["config"]["shape"]["N"] == N and rec["config"]["shape"]["d"] == d and rec["config"]["shape"]["H"] == H and rec["config"]["shape"]["Q"] == Q
+    # the same recall from the facade directly, against the file's neighbours
+    from nlsh_amd.data import SIFT
+    from nlsh_amd.indexer import Indexer
+    from nlsh_amd.metrics import calculate_recall
+    ix = Indexer(make_hashing(d, (48,), H, Ws, bs), dev(base), SIFT.distance)
+    ids, _ = ix.query(dev(query), k=10, hash_times=10, seed=5000)
+    assert abs(rec["recall_at_10"] - float(np.mean(calculate_recall(list(gt[:, :10]), ids)))) < 1e-12
