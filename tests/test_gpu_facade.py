@@ -388,3 +388,32 @@ def test_bench_runs_on_real_files_given_as_a_texmex_directory(tmp_path):
     ix = Indexer(make_hashing(d, (48,), H, Ws, bs), dev(base), SIFT.distance)
     ids, _ = ix.query(dev(query), k=10, hash_times=10, seed=5000)
     assert abs(rec["recall_at_10"] - float(np.mean(calculate_recall(list(gt[:, :10]), ids)))) < 1e-12
+
+
+def test_train_hash_tool_on_a_texmex_directory(tmp_path):
+    """tools/train_hash.py --dataset: the minimal triplet trainer (N2) on files read through the dataset classes (N4); the checkpoint it
+    writes loads back through io.load_hasher_weights and its validation history went through the HIP Indexer."""
+    import json
+    import subprocess
+    import sys
+    from nlsh_amd import io
+    from nlsh_amd.data import brute_force_topk
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    N, Q, d = 6000, 200, 24
+    base = synth.sift_like(N, d, seed=31)
+    query = synth.sift_like(Q, d, seed=32)
+    gt = brute_force_topk(dev(query), dev(base), 10, "l2").cpu().numpy().astype(np.int32)
+    root = tmp_path / "toy"
+    root.mkdir()
+    io.write_vecs(str(root / "toy_base.fvecs"), base)
+    io.write_vecs(str(root / "toy_query.fvecs"), query)
+    io.write_vecs(str(root / "toy_groundtruth.ivecs"), gt)
+    out_path = tmp_path / "h.npz"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_hash.py"), "--dataset", str(root), "--metric", "l2", "--unit-norm",
+                          "--hash-size", "8", "--steps", "120", "--every", "60", "--q", str(Q), "--out", str(out_path)],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    last = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert 0.0 <= last["test/recall"] <= 1.0 and last["test/query_size"] > 0          # the reference's metric names (base.py:105-108)
+    Ws, bs = io.load_hasher_weights(str(out_path))
+    assert [w.shape for w in Ws] == [(256, d), (256, 256), (8, 256)] and all(b is not None for b in bs)
