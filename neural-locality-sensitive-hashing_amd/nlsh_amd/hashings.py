@@ -127,9 +127,10 @@ class MultivariateBernoulli:
         call, so it walks a cached list of the modules' own `_parameters` / `_buffers` dicts (a reassigned tensor is seen through the
         dict) instead of `module.parameters()` -- the recursive module walk cost 30 us per call, a third of the host time of a pipelined
         batch (r04, cProfile of `QueryPipeline.submit`).  Submodules ADDED after the first call are not seen: rebuild the hashing."""
-        slots = self.__dict__.get("_sig_slots")
-        if slots is None:
-            slots = self._sig_slots = [(d, name) for m in self._hasher.modules() for d in (m._parameters, m._buffers) for name in d]
+        cached = self.__dict__.get("_sig_slots")
+        if cached is None or cached[0] is not self._hasher:           # a replaced `_hasher` module gets its own walk
+            cached = self._sig_slots = (self._hasher, [(d, name) for m in self._hasher.modules() for d in (m._parameters, m._buffers) for name in d])
+        slots = cached[1]
         sig = []
         for d, name in slots:
             t = d.get(name)
