@@ -246,6 +246,19 @@ class OracleIndexer:
         self.corpus_keys = keys[:, 0].copy()
         self.perm, self.uniq_keys, self.offsets = build_csr(self.corpus_keys)
 
+    @classmethod
+    def from_keys(cls, corpus, corpus_keys, metric="l2", key_mode="ref_int16"):
+        """An oracle index over rows whose bucket keys are GIVEN (one per row, as recorded from another run of the same hash):
+        the scan stage of nlsh/indexer.py:56-96 on an identical index, independent of hashing.  Full-size parity
+        tests use it with the device's keys, so that the oracle does not have to push 10^6..10^8 rows through its scalar MLP."""
+        self = cls.__new__(cls)
+        self.Ws = self.bs = None
+        self.act, self.key_mode, self.seed, self.metric = "sigmoid", key_mode, 0, metric
+        self.corpus = np.ascontiguousarray(corpus, dtype=np.float32)
+        self.corpus_keys = np.ascontiguousarray(corpus_keys, dtype=np.int64)
+        self.perm, self.uniq_keys, self.offsets = build_csr(self.corpus_keys)
+        return self
+
     @property
     def index2row(self):
         return {int(k): self.perm[self.offsets[i]:self.offsets[i + 1]].astype(np.int64)
@@ -264,11 +277,12 @@ class OracleIndexer:
         keys, nk = self.hash_arrays(x, batch_size, hash_times)
         return [set(int(v) for v in keys[i, :nk[i]]) for i in range(len(nk))]
 
-    def query_with_keys(self, queries, key_lists, k=10):
-        """Scan stage on injected key lists (each in the set-iteration order the caller saw)."""
+    def query_with_keys(self, queries, key_lists, k=10, simd=False):
+        """Scan stage on injected key lists (each in the set-iteration order the caller saw).
+        simd=True: the AVX2/OpenMP form of the scan (bit-identical to the scalar one, tests/test_oracle_golden.py)."""
         qk, nk = keys_from_lists(key_lists)
         od, oi, nc = query_batch(self.corpus, self.perm, self.uniq_keys, self.offsets, queries, qk, nk, k,
-                                 self.metric)
+                                 self.metric, simd=simd)
         i2r = None
         results = []
         for q in range(len(key_lists)):

@@ -4,13 +4,16 @@ checkpoints/deep100m_manifold_h32.npz, trained by tools/scale_deep100m.py --save
 generator), 100,000 queries, k = 10, hash_times = 10.  (The 8-rank form of this config shards these rows; one GPU holds
 them all, so every kernel runs at the full problem size here.)
 
-The oracle cannot brute-force this size.  Parity =
+Parity =
 * the size-independent properties of `helpers.check_scan_properties` on ALL 100 k queries (candidate counts recomputed
   independently, membership of every returned id in a probed bucket, ascending order, no duplicates, distances vs stock
   torch ops on the returned rows);
-* the oracle on a 64-query slice, fed with ONLY the rows of the buckets those queries probe (gathered on the device, a
+* the scalar oracle on a 64-query slice, fed with ONLY the rows of the buckets those queries probe (gathered on the device, a
   ~1 GB host copy instead of 38 GB), arranged so that its (distance, row id) tie order is the global one: ids and candidate
   counts exact, L2 distances bit-identical (tiled schedule: same k-ascending fmaf chain);
+* the oracle's AVX2/OpenMP scan (pinned bit-identical to the scalar form, tests/test_oracle_golden.py) on 4,096 queries spread
+  over the whole batch, against a host copy of the WHOLE corpus (38.4 GB) and the index's own bucket lists after the grouping has
+  been verified in full on the device: ~2 * 10^8 (query, candidate) pairs, ids / counts / distance bits exact;
 * the hard keys of a corpus slice against the oracle's forward + full-width pack."""
 import os
 import sys
@@ -97,6 +100,31 @@ def test_deep100m_full_size_one_gpu():
         oi_global = np.where(oi >= 0, back[np.clip(oi, 0, tot - 1)], -1)
         assert np.array_equal(idx[:S].cpu().numpy(), oi_global)
         assert np.array_equal(dist[:S].cpu().numpy().view(np.uint32), od.view(np.uint32))   # bit-identical L2 distances
+
+        # ---- oracle (SIMD form) on 4,096 queries over the whole batch, on the whole corpus
+        # the index's grouping verified IN FULL first, so the oracle may walk the device's bucket lists: a permutation of the rows,
+        # buckets in ascending signed key order, rows ascending inside a bucket = what a stable sort by key yields (nlsh/indexer.py:6-24)
+        permL = ix.perm.long()
+        assert torch.equal(torch.sort(ix.perm).values, torch.arange(N, device=device, dtype=torch.int32))
+        sk = ckeys[permL]
+        assert bool((sk[1:] >= sk[:-1]).all())
+        same = sk[1:] == sk[:-1]
+        assert bool((ix.perm[1:][same] > ix.perm[:-1][same]).all())
+        heads = torch.nonzero(~same).view(-1) + 1
+        assert torch.equal(ix.offsets[1:-1].long(), heads) and torch.equal(ix.uniq_keys, sk[ix.offsets[:-1].long()])
+        assert ix.row_ids is None and torch.equal(ix.gid, ix.perm)               # ids the scan reports = the rows' global ids
+        del permL, sk, same, heads
+        S2 = 4096
+        pick = torch.arange(S2, device=device) * (Q // S2)                       # every 24th query of the batch
+        corpus_h = cg.cpu().numpy()                                              # 38.4 GB of host memory for the length of this block
+        od, oi, onc = oracle.query_batch(corpus_h, ix.perm.cpu().numpy(), ix.uniq_keys.cpu().numpy().astype(np.int64),
+                                         ix.offsets.cpu().numpy().astype(np.int64), qg[pick].cpu().numpy(),
+                                         keys[pick].cpu().numpy().astype(np.int64), nkeys[pick].cpu().numpy(), k, "l2", simd=True)
+        del corpus_h
+        assert np.array_equal(nc[pick].cpu().numpy(), onc)
+        assert np.array_equal(idx[pick].cpu().numpy(), oi)
+        assert np.array_equal(dist[pick].cpu().numpy().view(np.uint32), od.view(np.uint32))
+        print(f"[oracle, Deep100M] {S2} queries x {onc.mean():.0f} candidates bit-identical ({onc.sum() / 1e6:.0f} M pairs)")
 
         # ---- the opt-in folded L2 form on ALL 100 k queries: differences from the exact form are ties at the stated tolerance only
         from helpers import l2_forms_differ_only_at_ties

@@ -1,6 +1,8 @@
-"""Full-size (BASELINE.json configs[1]: 1M x 128-d, 10k queries, 16-bit learned hash) property tests.
-The oracle cannot brute-force this size in seconds, so parity is checked through size-independent
-properties plus an oracle check on a slice of the queries."""
+"""Full-size (BASELINE.json configs[1]: 1M x 128-d, 10k queries, 16-bit learned hash) tests: size-independent properties,
+and the CPU oracle on ALL 10^4 queries -- its AVX2/OpenMP scan (pinned bit-identical to the scalar restatement,
+tests/test_oracle_golden.py) answers the whole batch at 2,400 candidates per query in well under a second on the box's cores, so
+every query, including the single-probe tail (rows >= 8192, F6, nlsh/indexer.py:51-53) and the queries with fewer than k
+candidates (F7, nlsh/indexer.py:89-93), is compared bit for bit, not sampled."""
 import os
 
 import numpy as np
@@ -88,7 +90,8 @@ def test_results_properties_and_schedule_agreement(sift1m):
 
 
 def test_oracle_on_a_query_slice(sift1m):
-    """First 64 queries of the full-size index against the CPU oracle (bit-exact for the tiled schedule)."""
+    """First 64 queries of the full-size index against the SCALAR oracle (bit-exact for the tiled schedule); the whole batch
+    goes through the oracle's SIMD form in test_oracle_on_all_queries_and_reference_typed_lists."""
     ix = sift1m["indexers"]["tiled"]
     qg = sift1m["qg"][:64]
     keys, nkeys = ix._hashing.hash_device(qg, n=10, seed=77)
@@ -104,6 +107,35 @@ def test_oracle_on_a_query_slice(sift1m):
     _, p01 = oracle.head_probs(z)
     ko, _ = oracle.row_keys(p01, 1, "ref_int16")
     assert np.array_equal(ko[:, 0], ix.corpus_keys[:4096].cpu().numpy())
+
+
+def test_oracle_on_all_queries_and_reference_typed_lists(sift1m):
+    """all 10^4 queries of configs[1] against the oracle -- candidate counts and ids exact, tiled-L2 distance bits
+    equal -- and the reference-typed `query()` lists (nlsh/indexer.py:56-96) against the oracle's restatement of the same rule, so that
+    the F6 single-probe tail (rows >= 8192) and every F7 short query are oracle-checked rather than property-checked."""
+    ix = sift1m["indexers"]["tiled"]
+    qg, k, P, seed = sift1m["qg"], 10, 10, 5000
+    Q = qg.shape[0]
+    keys, nkeys = ix.hash_device(qg, hash_times=P, seed=seed)                   # Indexer.hash's batching rule included (F6)
+    dist, idx, nc, _ = ix.scan_tensors(qg, keys, nkeys, k=k)
+    kh, nh = keys.cpu().numpy().astype(np.int64), nkeys.cpu().numpy()
+    assert int(nh[:8192].max()) > 1 and int(nh[8192:].max()) == 1
+    ox = oracle.OracleIndexer.from_keys(sift1m["corpus"], ix.corpus_keys.cpu().numpy())
+    assert np.array_equal(ox.perm, ix.perm.cpu().numpy()) and np.array_equal(ox.offsets, ix.offsets.cpu().numpy())
+    od, oi, onc = oracle.query_batch(ox.corpus, ox.perm, ox.uniq_keys, ox.offsets, sift1m["queries"], kh, nh, k, "l2", simd=True)
+    assert np.array_equal(nc.cpu().numpy(), onc)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.array_equal(dist.cpu().numpy().view(np.uint32), od.view(np.uint32))
+    # the reference's return types, through the facade's own call (same seed -> same keys), against the oracle's F7 rule
+    ids, ncand = ix.query(qg, k=k, hash_times=P, seed=seed)
+    key_lists = [list(set(int(v) for v in kh[i, :nh[i]])) for i in range(Q)]      # the set's iteration order (utils.pyx:27-31)
+    ores, oncl, _, _ = ox.query_with_keys(sift1m["queries"], key_lists, k, simd=True)
+    assert ncand == oncl
+    assert ids == ores
+    short = [i for i in range(Q) if oncl[i] < k]
+    assert short and any(i >= 8192 for i in short), "the workload is expected to hold short queries, some in the single-probe tail"
+    assert all(len(ids[i]) == oncl[i] or len(key_lists[i]) > 1 for i in short)     # F7: the LAST key's rows only
+    print(f"[oracle, SIFT1M] all {Q} queries bit-identical; {len(short)} short queries (F7), {sum(i >= 8192 for i in short)} of them in the F6 tail")
 
 
 def test_recall_matches_bench_claim(sift1m):
