@@ -149,6 +149,30 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def collective_facts(world, dev, gpus):
+    """What the N>1 line says about the exchange it ran, OBSERVED through the data backend itself: the backend's
+    name, the number of ranks an all-reduce of ones saw, and the number of distinct devices among the ranks (all-gather of each rank's
+    PCI identity; 1 on the one-GPU rehearsals, N on a real node).  A line whose collective did not see --gpus ranks is never printed."""
+    if world == 1:
+        return None
+    backend = dist.get_backend()
+    on = dev if backend == "nccl" else torch.device("cpu")       # gloo rehearsals exchange host tensors
+    seen = torch.ones((1,), dtype=torch.int64, device=on)
+    dist.all_reduce(seen)
+    props = torch.cuda.get_device_properties(dev)
+    ident = (int(getattr(props, "pci_domain_id", 0)) << 32) | (int(getattr(props, "pci_bus_id", 0)) << 8) | int(getattr(props, "pci_device_id", 0))
+    ident = (ident << 8) | (dev.index & 0xFF)
+    mine = torch.tensor([ident], dtype=torch.int64, device=on)
+    table = torch.empty((world,), dtype=torch.int64, device=on)
+    dist.all_gather_into_tensor(table, mine)
+    facts = {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "world_size_seen": int(seen.item()),
+             "distinct_devices": int(torch.unique(table).numel()), "data_tensors_on": on.type}
+    if facts["world_size_seen"] != gpus:
+        print(f"[bench] the {backend} all-reduce saw {facts['world_size_seen']} ranks, --gpus says {gpus}: refusing to print a line", file=sys.stderr)
+        sys.exit(2)
+    return facts
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -183,6 +207,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    collective = collective_facts(world, dev, args.gpus)
 
     from nlsh_amd import _capi, synth
     from nlsh_amd.data import Glove, SIFT, brute_force_topk
@@ -580,6 +605,8 @@ def main():
             "scaling_value_key": "device_resident_qps",
             "scaling_ceiling_note": "per-rank pipelined local step emulated on one GPU: x1.7 / x2.4 / x3.0 at N = 2 / 4 / 8 before the all-gather (replicated per-batch kernels; host enqueue time at N = 8)",
             "own_slice_qps": None if elapsed_own is None else Q * steps / elapsed_own,
+            # N>1 only: the exchange as the data backend itself saw it (ranks counted by an all-reduce of ones, devices by an all-gather of PCI ids)
+            "collective": collective,
             "protocol_median_qps": Q / float(np.median(call_s)),
             "protocol_call_ms": [round(1e3 * c, 3) for c in call_s],
             "device_resident_qps": Q * steps / elapsed_dev, "device_resident_ms_per_step": 1e3 * elapsed_dev / steps,

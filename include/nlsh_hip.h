@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NLSH_ABI_VERSION 2   /* 2 (r04): cells (nlsh_build_cells, nlsh_scan_topk_cells_phase); nlsh_scan_workspace_layout reports the row ranges */
+#define NLSH_ABI_VERSION 3   /* 3 (r05): pipelined batch slots (nlsh_step_*, nlsh_query_step_enqueue); 2 (r04): cells */
 
 typedef void *nlsh_stream_t; /* hipStream_t */
 
@@ -233,6 +233,64 @@ int nlsh_scan_topk_cells_phase(const float *corpus_sorted, int64_t row_stride, i
                                float *out_dist, int32_t *out_idx, uint64_t *out_keys, int32_t *out_ncand,
                                int32_t *status, void *workspace, size_t workspace_bytes, int64_t max_tasks,
                                void *ev_scan_begin, void *ev_scan_end, nlsh_stream_t stream, int phases);
+
+/* ---------------------------------------------------------------------------------------------
+ * One pipelined query batch per call.  Replaces, for a caller that streams batches, the whole body of Indexer.query
+ * (nlsh/indexer.py:56-96: hashing.hash on the batch :59 via Indexer.hash :40-54, then the per-query loop :62-95) by ONE
+ * enqueue: nlsh_encode_hash + the PLAN, SCAN and MERGE phases of nlsh_scan_topk_cells_phase (seven launches) and the events
+ * that order them across three or four streams.  A step (slot) is built once from everything that does not change between
+ * batches of one shape; nlsh_query_step_enqueue then takes the batch pointer, its row stride and the Philox seed.  The library
+ * owns the slot's events; streams and buffers are the caller's.  Results are those of the separate calls, bit for bit.
+ *
+ *   front:  encode(i+1) plan(i+1)         | ...          (plan on its own stream when `plan` is not NULL: four stages)
+ *   mid  :  scan(i)                       | ...
+ *   tail :  merge(i-1) [caller's work]    | ...
+ *
+ * A slot is reused when its previous batch has left the tail stream (event, waited for on the device by the next enqueue).
+ * hold_done != 0: the caller queues more work on the tail stream after the merge (a sharded index's all-gather + shard merge)
+ * and then calls nlsh_step_release, which marks the slot's batch as finished at that point of the tail stream.
+ * A failed enqueue leaves the slot's workspace in an undefined state (workspace contract above): destroy the step.
+ * Not thread-safe: one host thread per step.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct nlsh_step nlsh_step_t;
+typedef struct nlsh_step_desc {
+    /* hash function: the arguments of nlsh_encode_hash that do not change from batch to batch (dims [host] is copied) */
+    int32_t n_layers, act, key_mode, n_probes;
+    const int *dims;
+    const float *packed;
+    int64_t n_multi_rows;
+    /* index: the arguments of nlsh_scan_topk_cells_phase in its order */
+    const float *corpus_sorted;
+    int64_t row_stride;
+    const int32_t *gid, *uniq_keys, *offsets, *bucket_order, *cell_of, *cell_offsets;
+    const float *inv_norm;
+    int32_t d, n_buckets, n_cells, k, metric, algo, seg_rows, hold_done;
+    /* batch shape and the slot's own buffers (qkeys [Q, n_probes] and nkeys [Q] are written by the encode, read by the scan) */
+    int64_t Q;
+    int32_t *qkeys, *nkeys;
+    float *out_dist;
+    int32_t *out_idx;
+    uint64_t *out_keys;
+    int32_t *out_ncand, *status;
+    void *workspace;
+    size_t workspace_bytes;
+    int64_t max_tasks;
+    /* streams (hipStream_t): front, mid, tail must be three different non-default streams; plan may be NULL */
+    nlsh_stream_t front, plan, mid, tail;
+} nlsh_step_desc_t;
+
+/* desc_bytes = sizeof(nlsh_step_desc_t) of the CALLER's header: a binding built against another layout is refused. */
+int nlsh_step_create(const nlsh_step_desc_t *desc, size_t desc_bytes, nlsh_step_t **step_out);
+int nlsh_step_destroy(nlsh_step_t *step);
+/* New packed weights (nlsh_encoder_pack) for the batches enqueued from now on (a training step between two batches). */
+int nlsh_step_set_weights(nlsh_step_t *step, const float *packed);
+/* queries [dev] fp32 [Q, d] with row stride q_stride.  producer (nullable): the stream the batch was produced on -- the front
+ * stream waits for what is queued there now.  ev_scan_begin / ev_scan_end (nullable hipEvent_t): recorded around the scan kernel. */
+int nlsh_query_step_enqueue(nlsh_step_t *step, const float *queries, int64_t q_stride, uint64_t seed, nlsh_stream_t producer,
+                            void *ev_scan_begin, void *ev_scan_end);
+int nlsh_step_release(nlsh_step_t *step);   /* hold_done steps only: the batch ends HERE on the tail stream */
+/* 1 while the slot's last batch has not left the tail stream, 0 once it has, < 0 on error.  Never blocks. */
+int nlsh_step_busy(nlsh_step_t *step);
 
 /* Merge G per-shard top-k lists per query (keys_in [dev] [G, Q, row_stride] u64, the first k of each
  * row as all-gathered from nlsh_scan_topk's out_keys) into the global top-k; same comparator, so the

@@ -23,33 +23,13 @@
 //     S = width+4 floats with S/4 odd makes those reads conflict-free;
 //   * bias + ReLU are fused into the accumulator write-back; sigmoid/tanh, the `> 0.5` bit rule,
 //     MSB-first packing, Philox Bernoulli probes and per-row de-duplication are the epilogue.
-#include "common.h"
+#include <atomic>
+
+#include "encode_common.h"
 
 namespace nlsh {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct LayerDesc {
-    int K, N;      // logical in/out width
-    int Kp, Np;    // padded: Kp % 8 == 0, Np % 32 == 0
-    long long w_off, b_off;  // float offsets into the packed blob
-    long long w16_off;       // the same weights packed for 16x16x4 tiles (hidden layers: a second copy behind the blob; output layer: == w_off)
-};
-
-struct EncArgs {
-    const float *x;
-    long long n, x_stride;
-    int n_layers;
-    LayerDesc L[NLSH_MAX_LAYERS];
-    const float *packed;
-    int S;  // LDS row stride (floats)
-    int H, act, key_mode, n_probes;
-    long long n_multi_rows, row0;
-    unsigned long long seed;
-    float *z_out, *probs_out;
-    uint32_t *code_out;
-    int32_t *keys_out, *nkeys_out;
-};
 
 // position of logical column k inside an LDS row: within each group of 8, evens first then odds
 // so that lane half h reads k = 8c+h, 8c+2+h, 8c+4+h, 8c+6+h as one 16-byte word at 8c+4h.
@@ -84,6 +64,8 @@ __device__ __forceinline__ void philox4x32_10(unsigned long long seed, uint32_t 
 #ifndef NLSH_ENC_H16_MAX_ROWS
 #define NLSH_ENC_H16_MAX_ROWS 4096
 #endif
+// (r05: 48-row workgroups of THREE 16-row tiles sharing every B fragment -- one workgroup per CU for 8192 < rows <= 12288 instead of two 32-row
+// ones on some CUs -- measured 44.4 us against 37.2 us on the 10^4-query batch and were removed: profiles/r05_encoder_48row_form_ab.txt.)
 
 // Diagnostic build only (make EXTRA=-DNLSH_ENC_TRACE, tools/enc_trace.py): thread 0 of every workgroup
 // leaves the 100 MHz wall_clock64 stamp of each phase boundary in the first floats of its z_out rows.
@@ -107,8 +89,8 @@ __device__ __forceinline__ void philox4x32_10(unsigned long long seed, uint32_t 
 // the rows.  It IS the shorter critical path while there is at most one workgroup per CU: batches of <= 4096 rows (24.5 vs 27.2 us).
 template <int RT, int NW, bool SINGLE, int MT = 1, int WPE = 1, bool H16 = false>  // MT: column tiles a wave may own in SINGLE mode (1: width <= 32*NW); WPE: waves per SIMD the registers must allow
 __global__ __launch_bounds__(NW * 64, WPE) void encode_hash_kernel(EncArgs a) {
-    constexpr int M = H16 ? 16 : 32 * RT;
-    static_assert(!H16 || (SINGLE && RT == 1), "the 16-row form runs on a single LDS image");
+    constexpr int M = H16 ? 16 * RT : 32 * RT;   // H16: RT row tiles of 16 sharing every B fragment (shipped: RT = 1; RT = 3 measured and dropped in r05)
+    static_assert(!H16 || SINGLE, "the 16-row-tile form runs on a single LDS image");
     constexpr int NTH = NW * 64;
     extern __shared__ float4 smem4[];
     float *smem = reinterpret_cast<float *>(smem4);
@@ -188,12 +170,13 @@ __global__ __launch_bounds__(NW * 64, WPE) void encode_hash_kernel(EncArgs a) {
             const int pa = ((g & 1) << 2) + (g >> 1);   // pos(g) inside a chunk; pos(4 + g) = pa + 2
             const float *arow = in + (size_t)l16 * S + pa;
             constexpr int OR = 4;                        // B ring per tile: groups of 16 k in flight
-            f32x4v acc[MT];
+            f32x4v acc[MT][RT];                          // RT row tiles share every B fragment: MT * RT independent MFMA chains per wave
             float4 B[MT][OR];
             const float4 *w0[MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                acc[m] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[m][rt] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
                 const int ct = min(wave + m * NW, ct16 - 1);   // tiles past the layer's width redo its last one (valid addresses), results dropped
                 w0[m] = W16 + (size_t)ct * ngr * 64 + lane;
 #pragma unroll
@@ -212,18 +195,31 @@ __global__ __launch_bounds__(NW * 64, WPE) void encode_hash_kernel(EncArgs a) {
                                 B[m][jj] = w0[m][(size_t)min(j + OR, ngr - 1) * 64];
                             }
                             const int c0 = 2 * j, c1 = 2 * j + 1;
-                            const float a0 = arow[c0 * 8], a1 = arow[c0 * 8 + 2];
                             const bool two = c1 < nch;   // Kp is a multiple of 8, not of 16: the last group may hold one chunk only
-                            const float a2 = two ? arow[c1 * 8] : 0.0f, a3 = two ? arow[c1 * 8 + 2] : 0.0f;
+                            float a0[RT], a1[RT], a2[RT], a3[RT];
 #pragma unroll
-                            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bq[m].x, acc[m], 0, 0, 0);
+                            for (int rt = 0; rt < RT; ++rt) {
+                                const float *ar = arow + (size_t)rt * 16 * S;
+                                a0[rt] = ar[c0 * 8]; a1[rt] = ar[c0 * 8 + 2];
+                                a2[rt] = two ? ar[c1 * 8] : 0.0f; a3[rt] = two ? ar[c1 * 8 + 2] : 0.0f;
+                            }
 #pragma unroll
-                            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bq[m].y, acc[m], 0, 0, 0);
+                            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                                for (int rt = 0; rt < RT; ++rt) acc[m][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[rt], bq[m].x, acc[m][rt], 0, 0, 0);
+#pragma unroll
+                            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                                for (int rt = 0; rt < RT; ++rt) acc[m][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[rt], bq[m].y, acc[m][rt], 0, 0, 0);
                             if (two) {
 #pragma unroll
-                                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bq[m].z, acc[m], 0, 0, 0);
+                                for (int m = 0; m < MT; ++m)
 #pragma unroll
-                                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bq[m].w, acc[m], 0, 0, 0);
+                                    for (int rt = 0; rt < RT; ++rt) acc[m][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[rt], bq[m].z, acc[m][rt], 0, 0, 0);
+#pragma unroll
+                                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                                    for (int rt = 0; rt < RT; ++rt) acc[m][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[rt], bq[m].w, acc[m][rt], 0, 0, 0);
                             }
                         }
                     }
@@ -239,14 +235,18 @@ __global__ __launch_bounds__(NW * 64, WPE) void encode_hash_kernel(EncArgs a) {
                     const float bias = Bp[col];
                     if (last) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) out[(4 * g + i) * 33 + col] = acc[m][i] + bias;   // z, natural column order
+                        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) out[(rt * 16 + 4 * g + i) * 33 + col] = acc[m][rt][i] + bias;   // z, natural column order
                     } else {
                         const int pc = pos(col);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {   // bias + ReLU (encoders.py:19-20); C/D map: col = lane & 15, row = 4 * (lane >> 4) + i
-                            const float v = acc[m][i] + bias;
-                            out[(size_t)(4 * g + i) * S + pc] = v > 0.0f ? v : 0.0f;
-                        }
+                        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {   // bias + ReLU (encoders.py:19-20); C/D map: col = lane & 15, row = 4 * (lane >> 4) + i
+                                const float v = acc[m][rt][i] + bias;
+                                out[(size_t)(rt * 16 + 4 * g + i) * S + pc] = v > 0.0f ? v : 0.0f;
+                            }
                     }
                 }
             }
@@ -646,23 +646,22 @@ extern "C" int nlsh_pack_codes(const int32_t *codes, int64_t B, int n, int H, in
     return NLSH_OK;
 }
 
-extern "C" int nlsh_encode_hash(const float *x, int64_t n, int64_t x_stride, int n_layers, const int *dims,
-                                const float *packed, int act, int key_mode, int n_probes, int64_t n_multi_rows,
-                                uint64_t seed, int64_t row0, float *z_out, float *probs_out, uint32_t *code_out,
-                                int32_t *keys_out, int32_t *nkeys_out, nlsh_stream_t stream) {
+namespace nlsh {
+
+int encode_plan_fill(EncPlan &p, int64_t n, int n_layers, const int *dims, const float *packed, int act, int key_mode, int n_probes,
+                     int64_t n_multi_rows, int64_t row0, float *z_out, float *probs_out, uint32_t *code_out, int32_t *keys_out,
+                     int32_t *nkeys_out) {
     int rc = check_dims(n_layers, dims);
     if (rc != NLSH_OK) return rc;
     NLSH_REQUIRE(n >= 0, NLSH_E_INVALID, "encode_hash: n=%lld", (long long)n);
-    if (n == 0) return NLSH_OK;
-    NLSH_REQUIRE(x && packed && keys_out && nkeys_out, NLSH_E_INVALID, "encode_hash: null pointer");
-    NLSH_REQUIRE(x_stride >= dims[0], NLSH_E_INVALID, "encode_hash: x_stride %lld < d %d", (long long)x_stride, dims[0]);
+    NLSH_REQUIRE(n == 0 || (packed && keys_out && nkeys_out), NLSH_E_INVALID, "encode_hash: null pointer");
     NLSH_REQUIRE(act == NLSH_ACT_SIGMOID || act == NLSH_ACT_TANH, NLSH_E_INVALID, "encode_hash: act=%d", act);
     NLSH_REQUIRE(key_mode == NLSH_KEY_REF_INT16 || key_mode == NLSH_KEY_FULL, NLSH_E_INVALID, "encode_hash: key_mode=%d", key_mode);
     // hashings.py:83: "`n` should be positive integer"
     NLSH_REQUIRE(n_probes >= 1 && n_probes <= NLSH_MAX_ENCODE_PROBES, NLSH_E_INVALID, "encode_hash: n_probes=%d not in [1,%d]", n_probes, NLSH_MAX_ENCODE_PROBES);
 
-    EncArgs a;
-    a.x = x; a.n = n; a.x_stride = x_stride; a.n_layers = n_layers; a.packed = packed;
+    EncArgs &a = p.a;
+    a.x = nullptr; a.n = n; a.x_stride = 0; a.n_layers = n_layers; a.packed = packed;
     long long total;
     fill_layers(n_layers, dims, a.L, &total);
     int maxKp = 64;
@@ -670,36 +669,32 @@ extern "C" int nlsh_encode_hash(const float *x, int64_t n, int64_t x_stride, int
     if (round_up(n_probes, 8) > maxKp) maxKp = round_up(n_probes, 8);  // the per-row key table [M][n_probes] reuses an activation image
     a.S = maxKp + 4;  // S/4 odd -> conflict-free ds_read_b128 of A fragments
     a.H = dims[n_layers]; a.act = act; a.key_mode = key_mode; a.n_probes = n_probes;
-    a.n_multi_rows = n_multi_rows; a.row0 = row0; a.seed = seed;
+    a.n_multi_rows = n_multi_rows; a.row0 = row0; a.seed = 0;
     a.z_out = z_out; a.probs_out = probs_out; a.code_out = code_out; a.keys_out = keys_out; a.nkeys_out = nkeys_out;
+    p.form = ENC_FORM_SINGLE; p.grid = 0; p.lds = 0;
+    if (n == 0) return NLSH_OK;
 
-    hipStream_t s = (hipStream_t)stream;
     const size_t lds_limit = 160 * 1024;
+    int max_np = 0;  // widest hidden layer decides how many column tiles a wave owns
+    for (int l = 0; l + 1 < n_layers; ++l) if (a.L[l].Np > max_np) max_np = a.L[l].Np;
     // Query-sized batches (and encoders too wide for two 64-row images) run 32-row workgroups on a SINGLE LDS image;
     // its rows must also hold the epilogue's z, p and key tables side by side (66 + n_probes floats per row).
     const bool single = n <= NLSH_ENC_SINGLE_MAX_ROWS || (size_t)2 * 64 * a.S * 4 > lds_limit;
     if (single) {
         if (72 + round_up(n_probes, 8) > maxKp) a.S = 72 + round_up(n_probes, 8) + 4;
-        size_t lds = (size_t)32 * a.S * 4;
-        NLSH_REQUIRE(lds <= lds_limit, NLSH_E_UNSUPPORTED, "encode_hash: width %d needs %zu B of LDS", maxKp, lds);
-        long long grid = (n + 31) / 32;
-        int max_np = 0;  // widest hidden layer decides how many column tiles a wave owns
-        for (int l = 0; l + 1 < n_layers; ++l) if (a.L[l].Np > max_np) max_np = a.L[l].Np;
-        if (n <= NLSH_ENC_H16_MAX_ROWS && max_np <= 16 * 8 * 2) {   // 16-row workgroups, every layer as 16x16x4 tiles (two column tiles per wave:
-            // 78 VGPRs, three workgroups per CU; wider encoders would need five tiles per wave = 175 VGPRs and stay on the 32-row form)
-            const size_t lds16 = (size_t)16 * a.S * 4;
-            NLSH_CHECK_HIP(hipFuncSetAttribute((const void *)encode_hash_kernel<1, 8, true, 2, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
-            hipLaunchKernelGGL((encode_hash_kernel<1, 8, true, 2, 1, true>), dim3((unsigned)((n + 15) / 16)), dim3(512), lds16, s, a);
+        p.lds = (size_t)32 * a.S * 4;
+        NLSH_REQUIRE(p.lds <= lds_limit, NLSH_E_UNSUPPORTED, "encode_hash: width %d needs %zu B of LDS", maxKp, p.lds);
+        p.grid = (unsigned)((n + 31) / 32);
+        const bool h16_ok = max_np <= 16 * 8 * 2;   // two 16-column tiles per wave: wider encoders would need five = 175 VGPRs and stay on the 32-row form
+        if (n <= NLSH_ENC_H16_MAX_ROWS && h16_ok) {
+            // 16-row workgroups, every layer as 16x16x4 tiles (78 VGPRs, three workgroups per CU)
+            p.form = ENC_FORM_H16; p.lds = (size_t)16 * a.S * 4; p.grid = (unsigned)((n + 15) / 16);
         } else if (max_np <= 32 * 8) {
-            NLSH_CHECK_HIP(hipFuncSetAttribute((const void *)encode_hash_kernel<1, 8, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((encode_hash_kernel<1, 8, true, 1>), dim3((unsigned)grid), dim3(512), lds, s, a);
+            p.form = ENC_FORM_SINGLE;
         } else {
-            NLSH_CHECK_HIP(hipFuncSetAttribute((const void *)encode_hash_kernel<1, 8, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((encode_hash_kernel<1, 8, true, 3>), dim3((unsigned)grid), dim3(512), lds, s, a);
+            p.form = ENC_FORM_SINGLE_WIDE;
         }
     } else {
-        int max_np = 0;
-        for (int l = 0; l + 1 < n_layers; ++l) if (a.L[l].Np > max_np) max_np = a.L[l].Np;
         if (72 + round_up(n_probes, 8) > maxKp) a.S = 72 + round_up(n_probes, 8) + 4;
         const size_t lds128 = (size_t)128 * a.S * 4;
         // r02 also measured two ways of putting a second workgroup on the CU so that one's staging, write-backs and epilogue run
@@ -711,16 +706,63 @@ extern "C" int nlsh_encode_hash(const float *x, int64_t n, int64_t x_stride, int
             // index builds: 128 rows per workgroup on ONE image (accumulators of the four row tiles held in registers across the
             // layer barrier): a B fragment feeds 16 MFMAs instead of 8 and the per-layer fixed cost (write-back, barriers, ring
             // prologue: ~2.5-3.8 us) is paid once per 128 rows instead of once per 64
-            NLSH_CHECK_HIP(hipFuncSetAttribute((const void *)encode_hash_kernel<4, 8, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128));
-            hipLaunchKernelGGL((encode_hash_kernel<4, 8, true, 1>), dim3((unsigned)((n + 127) / 128)), dim3(512), lds128, s, a);
+            p.form = ENC_FORM_BUILD128; p.lds = lds128; p.grid = (unsigned)((n + 127) / 128);
         } else {
             a.S = maxKp + 4;
-            size_t lds = (size_t)2 * 64 * a.S * 4;
-            NLSH_CHECK_HIP(hipFuncSetAttribute((const void *)encode_hash_kernel<2, 8, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            long long grid = (n + 63) / 64;
-            hipLaunchKernelGGL((encode_hash_kernel<2, 8, false, 1>), dim3((unsigned)grid), dim3(512), lds, s, a);
+            p.form = ENC_FORM_PINGPONG; p.lds = (size_t)2 * 64 * a.S * 4; p.grid = (unsigned)((n + 63) / 64);
         }
     }
+    return NLSH_OK;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel form) and process instead of once per launch (r04: a
+// runtime call of its own in front of every encode, on a path whose pipelined step is bound by the host's enqueue time): the
+// attribute is a permission, so it is raised to the whole 160 KB the first time a form runs on a device.
+static int allow_lds(int form, const void *fn) {
+    static std::atomic<unsigned> done[16];
+    int dev = 0;
+    NLSH_CHECK_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 16 && (done[dev].load(std::memory_order_acquire) >> form) & 1u) return NLSH_OK;
+    NLSH_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (dev >= 0 && dev < 16) done[dev].fetch_or(1u << form, std::memory_order_release);
+    return NLSH_OK;
+}
+
+int encode_plan_launch(const EncPlan &p, const float *x, int64_t x_stride, uint64_t seed, hipStream_t s) {
+    if (p.a.n == 0) return NLSH_OK;
+    NLSH_REQUIRE(x != nullptr, NLSH_E_INVALID, "encode_hash: null pointer");
+    NLSH_REQUIRE(x_stride >= p.a.L[0].K, NLSH_E_INVALID, "encode_hash: x_stride %lld < d %d", (long long)x_stride, p.a.L[0].K);
+    EncArgs a = p.a;
+    a.x = x; a.x_stride = x_stride; a.seed = seed;
+#define NLSH_ENC_LAUNCH(FORM, ...)                                                                 \
+    case FORM: {                                                                                   \
+        auto *fn = encode_hash_kernel<__VA_ARGS__>;                                                \
+        int rc = allow_lds(FORM, (const void *)fn);                                                \
+        if (rc != NLSH_OK) return rc;                                                              \
+        hipLaunchKernelGGL(fn, dim3(p.grid), dim3(512), p.lds, s, a);                              \
+    } break;
+    switch (p.form) {
+        NLSH_ENC_LAUNCH(ENC_FORM_H16, 1, 8, true, 2, 1, true)
+        NLSH_ENC_LAUNCH(ENC_FORM_SINGLE, 1, 8, true, 1)
+        NLSH_ENC_LAUNCH(ENC_FORM_SINGLE_WIDE, 1, 8, true, 3)
+        NLSH_ENC_LAUNCH(ENC_FORM_BUILD128, 4, 8, true, 1)
+        NLSH_ENC_LAUNCH(ENC_FORM_PINGPONG, 2, 8, false, 1)
+        default: NLSH_REQUIRE(false, NLSH_E_INVALID, "encode_hash: form %d", p.form);
+    }
+#undef NLSH_ENC_LAUNCH
     NLSH_CHECK_HIP(hipGetLastError());
     return NLSH_OK;
+}
+
+}  // namespace nlsh
+
+extern "C" int nlsh_encode_hash(const float *x, int64_t n, int64_t x_stride, int n_layers, const int *dims,
+                                const float *packed, int act, int key_mode, int n_probes, int64_t n_multi_rows,
+                                uint64_t seed, int64_t row0, float *z_out, float *probs_out, uint32_t *code_out,
+                                int32_t *keys_out, int32_t *nkeys_out, nlsh_stream_t stream) {
+    EncPlan p;
+    int rc = encode_plan_fill(p, n, n_layers, dims, packed, act, key_mode, n_probes, n_multi_rows, row0, z_out, probs_out, code_out,
+                              keys_out, nkeys_out);
+    if (rc != NLSH_OK) return rc;
+    return encode_plan_launch(p, x, x_stride, seed, (hipStream_t)stream);
 }

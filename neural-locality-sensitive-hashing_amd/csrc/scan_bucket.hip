@@ -80,6 +80,9 @@ extern "C" int nlsh_debug_scan_trace(float *host, int n_floats) {
 #endif
 #define NLSH_SLOT(wave, jq) (NLSH_DEAL_BLOCKS ? (wave) * QW + (jq) : (wave) + NW * (jq))
 
+#ifndef NLSH_LEAN_EPILOGUE
+#define NLSH_LEAN_EPILOGUE 1   // r05: square roots without the range scaling (one wave-uniform guard per list), sign-free key build for L2
+#endif
 #ifndef NLSH_FAST_KBLOCK
 #define NLSH_FAST_KBLOCK 1  // hand-scheduled k-blocks for full L2 tasks (0: compiler-scheduled loop everywhere, for A/B)
 #endif
@@ -868,6 +871,8 @@ __device__ __forceinline__ void l2_task(float4 *tile, const float4 *corpus4, lon
         for (int i = 0; i < SPT; ++i) tile[(sr + RPPt * i) * RSt + sc] = stg[i];
         NLSH_STAGE_SYNC();
         if (kb + 1 < nkb) stage_load(kb + 1);  // in flight while this k-block is computed
+        // (r05: the queries' published bounds requested HERE in front of the last k-block, whose staging registers are free, instead of
+        // behind it: the eight registers stay live across the 20 task bodies' joins -- 80 VGPRs, 6 waves per SIMD)
         [[maybe_unused]] const unsigned long long tc = SCAN_NOW();
         tr[0] += tb - ta;   // first barrier: the slowest wave's previous k-block
         tr[1] += tc - tb;   // own stage data (vmcnt) + LDS write + second barrier
@@ -984,8 +989,7 @@ __device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, lo
 #ifdef NLSH_SCAN_TRACE_CLOCK
     const unsigned long long core0 = __builtin_amdgcn_s_memtime();   // shader-clock counter beside the 100 MHz stamps: the clock held
 #endif
-    const int pair0 = __builtin_amdgcn_readfirstlane(desc.x);
-    const int nq = __builtin_amdgcn_readfirstlane(desc.y);
+    const int nq = __builtin_amdgcn_readfirstlane(desc.y);       // desc.x (first pair of the group) is the wave-level schedule's: the tiled tasks carry their query ids
     const int row0 = __builtin_amdgcn_readfirstlane(desc.z);
     const int nrows = __builtin_amdgcn_readfirstlane(desc.w);  // <= ROWS (the host fixes seg = ROWS)
     // queries are dealt round-robin over the waves (slot = wave + NW*jq): a group of 5 queries costs the
@@ -1122,6 +1126,7 @@ __device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, lo
     uint64_t tau_w[QW];
 #pragma unroll
     for (int jq = 0; jq < QW; ++jq) tau_w[jq] = jq < nqw ? global_tau_load(a.tauq + qid[jq]) : KEY_NONE;
+    constexpr bool LEAN = NLSH_LEAN_EPILOGUE && METRIC != NLSH_METRIC_COSINE;
 #pragma unroll
     for (int jq = 0; jq < QW; ++jq) {
         if (jq < nqw) {
@@ -1132,11 +1137,29 @@ __device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, lo
             const int rng = __builtin_amdgcn_readfirstlane(rng_v[jq]);
             const unsigned r_lo = (unsigned)(rng & 0xFFFF), r_n = (unsigned)(rng >> 16) - r_lo;
             uint64_t key[TPS];
+            // LEAN: every accumulator of the list at or above 2^-96 (wave-uniform test; NaN compares false and takes the general path)
+            // -> square roots without the range scaling, and a non-negative distance's order-preserving word is its bits with the sign set
+            bool lean = LEAN;
+            if (LEAN) {
+                float lo4 = acc[0][jq];
+#pragma unroll
+                for (int tl = 1; tl < TPS; ++tl) lo4 = fminf(lo4, acc[tl][jq]);
+                bool ok = lo4 >= 0x1p-96f;
+#pragma unroll
+                for (int tl = 0; tl < TPS; ++tl) ok = ok && acc[tl][jq] == acc[tl][jq];   // fminf drops a NaN operand: ask every one
+                lean = __ballot(!ok) == 0ull;
+            }
 #pragma unroll
             for (int tl = 0; tl < TPS; ++tl) {
-                const float dist = finish_distance<METRIC>(acc[tl][jq], myinv[tl]);
                 const bool mine = valid[tl] && (unsigned)(tl * 64 + lane) - r_lo < r_n;
-                const uint64_t kk = mine ? make_key(dist, mygid[tl]) : KEY_NONE;
+                uint64_t kk;
+                if (lean) {
+                    const float dist = sqrt_rn_unscaled(acc[tl][jq]);
+                    kk = ((uint64_t)(__builtin_bit_cast(uint32_t, dist) | 0x80000000u) << 32) | (uint32_t)mygid[tl];   // == make_key for dist >= +0
+                } else {
+                    kk = make_key(finish_distance<METRIC>(acc[tl][jq], myinv[tl]), mygid[tl]);
+                }
+                kk = mine ? kk : KEY_NONE;
                 key[tl] = kk < tau_g ? kk : KEY_NONE;  // beyond another list's k-th best: cannot reach the final top-k
             }
             uint64_t *out = a.partial + ((long long)t * (QW * NW) + NLSH_SLOT(wave, jq)) * a.k;
@@ -1185,12 +1208,9 @@ __device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, lo
 
 template <int METRIC, int QW, int NW, int TPS>
 __global__ __launch_bounds__(64 * NW, NLSH_TILED_MIN_WAVES) void bscan3_kernel(BArgs a) {
-    constexpr int NT = 64 * NW;              // threads per workgroup
     constexpr int KB = NLSH_TILED_KB;        // 16-byte chunks per k-block
     constexpr int RS = KB + 1;               // odd LDS row stride (16-byte slots) -> conflict-free column reads
     constexpr int ROWS = 64 * TPS;
-    constexpr int SPT = ROWS * KB / NT;      // staged 16-byte words per thread and stage
-    constexpr int RPP = NT / KB;             // rows covered by one pass of the workgroup
     __shared__ float4 tile[ROWS * RS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     [[maybe_unused]] const unsigned long long ts_entry = SCAN_NOW();

@@ -27,6 +27,10 @@
 #define NLSH_NO_STAGE_BARRIER 0
 #endif
 
+#ifndef NLSH_SELECT_SHORT_PATHS
+#define NLSH_SELECT_SHORT_PATHS 1   // select_k_smallest: lists with no / fewer than k present keys skip the cut search and its compaction (0: r04's single path, for A/B; same results)
+#endif
+
 namespace nlsh {
 
 template <int CTRL>
@@ -145,6 +149,28 @@ __device__ __forceinline__ uint64_t select_k_smallest(const uint64_t (&key)[NK],
         hi[i] = (uint32_t)(key[i] >> 32);
         lo[i] = (uint32_t)key[i];
         n += __popcll(__ballot(key[i] != KEY_NONE));
+    }
+    // r05: the two short cases first.  18-36 % of the tiled scan's lists reach this point with NO key below the query's published bound and
+    // 23-41 % with fewer than k (profiles/r05_epilogue_counters_and_ablations.txt): neither needs a cut, and the general compaction below
+    // spends six compares per key slot re-deriving "present" from a cut that takes everything.
+    if (NLSH_SELECT_SHORT_PATHS && n == 0) {
+        if (lane < k) out[lane] = KEY_NONE;
+        return KEY_NONE;
+    }
+    if (NLSH_SELECT_SHORT_PATHS && n < k) {
+        int base0 = 0;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            const bool sel = key[i] != KEY_NONE;
+            const unsigned long long m = __ballot(sel);
+            if (m) {   // wave-uniform: an absent tile costs one scalar compare
+                const int pos = base0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (sel) out[pos] = key[i];
+                base0 += __popcll(m);
+            }
+        }
+        if (lane >= base0 && lane < k) out[lane] = KEY_NONE;
+        return KEY_NONE;
     }
     uint32_t dk = 0xFFFFFFFFu, idk = 0xFFFFFFFFu;  // take everything present (hi of a present key < 0xFFFFFFFF)
     if (n >= k) {
@@ -291,6 +317,21 @@ __device__ __forceinline__ float row_partial(const float4 (&qv)[VPL], const bool
         }
     }
     return sacc;
+}
+
+// Correctly rounded sqrtf for x >= 2^-96 (and for +0, +inf and NaN, which come out as sqrtf gives them): the core of the sequence hipcc
+// emits for sqrtf -- v_sqrt_f32 (1 ulp), then the two one-ulp neighbours are tried against the residual x - s'*s computed by ONE fma each
+// -- without the x * 2^32 / * 2^-16 range scaling it wraps around that core for arguments below 2^-96 and without the class test that
+// passes zeros and infinities through (27 VALU per call as compiled, 11 here).  The tiled scan takes 16 square roots per lane and task;
+// callers hold the wave's arguments against 2^-96 first and fall back to sqrtf when any lies below (never on real distances: the smallest
+// is sqrt(d) * 1e-6 for a query that IS a corpus row).
+__device__ __forceinline__ float sqrt_rn_unscaled(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, s) - 1u), sp = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, s) + 1u);
+    const float rm = fmaf(-sm, s, x), rp = fmaf(-sp, s, x);
+    float r = rm <= 0.0f ? sm : s;
+    r = rp > 0.0f ? sp : r;
+    return r;
 }
 
 template <int METRIC>

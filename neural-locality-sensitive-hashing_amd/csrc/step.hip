@@ -1,0 +1,141 @@
+// One pipelined query batch per C-ABI call (nlsh_query_step_enqueue, ABI v3).
+//
+// A batch of the reference's `Indexer.query` (nlsh/indexer.py:56-96) is encode_hash + the PLAN, SCAN and MERGE phases of the scan:
+// seven kernel launches.  Pipelined over HIP streams (front: encode + PLAN | mid: SCAN | tail: MERGE [+ the shard exchange]) it
+// also needs eight to ten event records / waits, and through r04 the Python facade issued all of them one ctypes / torch call at a
+// time: ~0.09 ms of host time per batch, which on small shards (8 GPUs: scan 0.055-0.068 ms) WAS the step.  Here the slot -- the
+// validated encode launch, the scan call, the four streams and the slot's events -- is built once (nlsh_step_create) and a batch is
+// ONE call that only swaps the batch pointer, its row stride and the Philox seed.  The library owns the events (it is linked against
+// the HIP runtime the kernels use; ADVICE r04: the facade used to dlopen "libamdhip64.so" by name for them); the streams and every
+// buffer stay the caller's.  Same kernels, same arguments, same results as the phase calls: only where the launches are issued from
+// changes.
+#include <new>
+
+#include "encode_common.h"
+
+using namespace nlsh;
+
+struct nlsh_step {
+    EncPlan enc;
+    nlsh_step_desc_t d;
+    int dims[NLSH_MAX_LAYERS + 1];
+    hipEvent_t ready, encoded, planned, scanned, done;
+    bool done_pending;   // hold_done: the caller still has to release the batch (nlsh_step_release)
+};
+
+static int make_event(hipEvent_t *e) {
+    NLSH_CHECK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    return NLSH_OK;
+}
+
+extern "C" int nlsh_step_create(const nlsh_step_desc_t *desc, size_t desc_bytes, nlsh_step_t **out) {
+    NLSH_REQUIRE(desc && out, NLSH_E_INVALID, "step_create: null pointer");
+    NLSH_REQUIRE(desc_bytes == sizeof(nlsh_step_desc_t), NLSH_E_INVALID, "step_create: descriptor of %zu bytes, this library's is %zu (ABI %d)",
+                 desc_bytes, sizeof(nlsh_step_desc_t), NLSH_ABI_VERSION);
+    NLSH_REQUIRE(desc->front && desc->mid && desc->tail, NLSH_E_INVALID, "step_create: the front, mid and tail streams must be real streams (not the default stream)");
+    NLSH_REQUIRE(desc->n_layers >= 1 && desc->n_layers <= NLSH_MAX_LAYERS && desc->dims, NLSH_E_INVALID, "step_create: n_layers=%d", desc->n_layers);
+    NLSH_REQUIRE(desc->n_probes >= 1 && desc->n_probes <= NLSH_MAX_PROBES, NLSH_E_UNSUPPORTED, "step_create: n_probes=%d not in [1,%d] (one scan call per batch)",
+                 desc->n_probes, NLSH_MAX_PROBES);
+    NLSH_REQUIRE(desc->Q >= 1 && desc->dims[0] == desc->d, NLSH_E_INVALID, "step_create: Q=%lld, encoder input %d vs corpus dimension %d", (long long)desc->Q,
+                 desc->dims[0], desc->d);
+    nlsh_step *s = new (std::nothrow) nlsh_step();
+    NLSH_REQUIRE(s != nullptr, NLSH_E_INVALID, "step_create: out of host memory");
+    s->d = *desc;
+    for (int l = 0; l <= desc->n_layers; ++l) s->dims[l] = desc->dims[l];
+    s->d.dims = s->dims;
+    s->ready = s->encoded = s->planned = s->scanned = s->done = nullptr;
+    s->done_pending = false;
+    int rc = encode_plan_fill(s->enc, desc->Q, desc->n_layers, s->dims, desc->packed, desc->act, desc->key_mode, desc->n_probes, desc->n_multi_rows, 0,
+                              nullptr, nullptr, nullptr, desc->qkeys, desc->nkeys);
+    if (rc == NLSH_OK) rc = make_event(&s->ready);
+    if (rc == NLSH_OK) rc = make_event(&s->encoded);
+    if (rc == NLSH_OK) rc = make_event(&s->planned);
+    if (rc == NLSH_OK) rc = make_event(&s->scanned);
+    if (rc == NLSH_OK) rc = make_event(&s->done);
+    if (rc == NLSH_OK && hipEventRecord(s->done, (hipStream_t)desc->tail) != hipSuccess) {   // the slot starts out free
+        set_error("step_create: hipEventRecord failed");
+        rc = NLSH_E_HIP;
+    }
+    if (rc != NLSH_OK) {
+        nlsh_step_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return NLSH_OK;
+}
+
+extern "C" int nlsh_step_destroy(nlsh_step_t *s) {
+    if (!s) return NLSH_OK;
+    for (hipEvent_t e : {s->ready, s->encoded, s->planned, s->scanned, s->done})
+        if (e) (void)hipEventDestroy(e);
+    delete s;
+    return NLSH_OK;
+}
+
+extern "C" int nlsh_step_set_weights(nlsh_step_t *s, const float *packed) {
+    NLSH_REQUIRE(s && packed, NLSH_E_INVALID, "step_set_weights: null pointer");
+    s->enc.a.packed = packed;
+    s->d.packed = packed;
+    return NLSH_OK;
+}
+
+static int scan_phase(const nlsh_step *s, const float *queries, int64_t q_stride, void *ev0, void *ev1, nlsh_stream_t stream, int phases) {
+    const nlsh_step_desc_t &d = s->d;
+    return nlsh_scan_topk_cells_phase(d.corpus_sorted, d.row_stride, d.d, d.gid, d.uniq_keys, d.offsets, d.bucket_order, d.n_buckets, d.cell_of,
+                                      d.cell_offsets, d.n_cells, d.inv_norm, queries, q_stride, d.Q, d.qkeys, d.nkeys, d.n_probes, d.k, d.metric,
+                                      d.algo, d.seg_rows, d.out_dist, d.out_idx, d.out_keys, d.out_ncand, d.status, d.workspace, d.workspace_bytes,
+                                      d.max_tasks, ev0, ev1, stream, phases);
+}
+
+extern "C" int nlsh_query_step_enqueue(nlsh_step_t *s, const float *queries, int64_t q_stride, uint64_t seed, nlsh_stream_t producer,
+                                       void *ev_scan_begin, void *ev_scan_end) {
+    NLSH_REQUIRE(s && queries, NLSH_E_INVALID, "query_step_enqueue: null pointer");
+    NLSH_REQUIRE(!s->done_pending, NLSH_E_INVALID, "query_step_enqueue: the slot's previous batch was not released (nlsh_step_release)");
+    const hipStream_t front = (hipStream_t)s->d.front, mid = (hipStream_t)s->d.mid, tail = (hipStream_t)s->d.tail;
+    NLSH_CHECK_HIP(hipStreamWaitEvent(front, s->done, 0));            // the slot's previous batch has left the tail: its buffers are free
+    if (producer && (hipStream_t)producer != front) {                 // the batch may still be in flight on the stream that produced it
+        NLSH_CHECK_HIP(hipEventRecord(s->ready, (hipStream_t)producer));
+        NLSH_CHECK_HIP(hipStreamWaitEvent(front, s->ready, 0));
+    }
+    int rc = encode_plan_launch(s->enc, queries, q_stride, seed, front);
+    if (rc != NLSH_OK) return rc;
+    hipStream_t hp = front;
+    if (s->d.plan) {                                                  // four stages: the PLAN phase on a stream of its own behind the encode
+        hp = (hipStream_t)s->d.plan;
+        NLSH_CHECK_HIP(hipEventRecord(s->encoded, front));
+        NLSH_CHECK_HIP(hipStreamWaitEvent(hp, s->encoded, 0));
+    }
+    rc = scan_phase(s, queries, q_stride, nullptr, nullptr, hp, NLSH_PHASE_PLAN);
+    if (rc != NLSH_OK) return rc;
+    NLSH_CHECK_HIP(hipEventRecord(s->planned, hp));
+    NLSH_CHECK_HIP(hipStreamWaitEvent(mid, s->planned, 0));
+    rc = scan_phase(s, queries, q_stride, ev_scan_begin, ev_scan_end, mid, NLSH_PHASE_SCAN);
+    if (rc != NLSH_OK) return rc;
+    NLSH_CHECK_HIP(hipEventRecord(s->scanned, mid));
+    NLSH_CHECK_HIP(hipStreamWaitEvent(tail, s->scanned, 0));
+    rc = scan_phase(s, queries, q_stride, nullptr, nullptr, tail, NLSH_PHASE_MERGE);
+    if (rc != NLSH_OK) return rc;
+    if (s->d.hold_done) s->done_pending = true;                       // the caller queues more work on the tail stream (the shard exchange) first
+    else NLSH_CHECK_HIP(hipEventRecord(s->done, tail));
+    return NLSH_OK;
+}
+
+extern "C" int nlsh_step_release(nlsh_step_t *s) {
+    NLSH_REQUIRE(s, NLSH_E_INVALID, "step_release: null pointer");
+    NLSH_CHECK_HIP(hipEventRecord(s->done, (hipStream_t)s->d.tail));
+    s->done_pending = false;
+    return NLSH_OK;
+}
+
+extern "C" int nlsh_step_busy(nlsh_step_t *s) {
+    NLSH_REQUIRE(s, NLSH_E_INVALID, "step_busy: null pointer");
+    if (s->done_pending) return 1;
+    const hipError_t e = hipEventQuery(s->done);
+    if (e == hipSuccess) return 0;
+    if (e == hipErrorNotReady) {
+        (void)hipGetLastError();   // "not ready" is an answer, not a failure: do not leave it behind as the thread's last HIP error
+        return 1;
+    }
+    set_error("hipEventQuery failed: %s", hipGetErrorString(e));
+    return NLSH_E_HIP;
+}

@@ -28,6 +28,7 @@ SYMBOLS = (
     "nlsh_build_csr_workspace", "nlsh_build_csr", "nlsh_bucket_order_workspace", "nlsh_bucket_order", "nlsh_build_cells_workspace", "nlsh_build_cells", "nlsh_gather_rows",
     "nlsh_scan_workspace", "nlsh_scan_workspace_layout", "nlsh_scan_topk", "nlsh_scan_topk_phase", "nlsh_scan_topk_cells_phase",
     "nlsh_merge_topk",
+    "nlsh_step_create", "nlsh_step_destroy", "nlsh_step_set_weights", "nlsh_query_step_enqueue", "nlsh_step_release", "nlsh_step_busy",
 )
 
 
@@ -39,6 +40,21 @@ class NlshHipError(RuntimeError):
 
 _lib = None
 vp, i32, i64, u64, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_size_t
+
+
+class StepDesc(ctypes.Structure):
+    """`nlsh_step_desc_t` of include/nlsh_hip.h, field for field (nlsh_step_create checks sizeof against the library's)."""
+    _fields_ = [
+        ("n_layers", ctypes.c_int32), ("act", ctypes.c_int32), ("key_mode", ctypes.c_int32), ("n_probes", ctypes.c_int32),
+        ("dims", vp), ("packed", vp), ("n_multi_rows", i64),
+        ("corpus_sorted", vp), ("row_stride", i64),
+        ("gid", vp), ("uniq_keys", vp), ("offsets", vp), ("bucket_order", vp), ("cell_of", vp), ("cell_offsets", vp), ("inv_norm", vp),
+        ("d", ctypes.c_int32), ("n_buckets", ctypes.c_int32), ("n_cells", ctypes.c_int32), ("k", ctypes.c_int32),
+        ("metric", ctypes.c_int32), ("algo", ctypes.c_int32), ("seg_rows", ctypes.c_int32), ("hold_done", ctypes.c_int32),
+        ("Q", i64), ("qkeys", vp), ("nkeys", vp), ("out_dist", vp), ("out_idx", vp), ("out_keys", vp), ("out_ncand", vp), ("status", vp),
+        ("workspace", vp), ("workspace_bytes", sz), ("max_tasks", i64),
+        ("front", vp), ("plan", vp), ("mid", vp), ("tail", vp),
+    ]
 
 
 def build_library(force=False):
@@ -95,6 +111,15 @@ def lib():
     L.nlsh_scan_topk_cells_phase.argtypes = L.nlsh_scan_topk_phase.argtypes[:8] + [vp, vp, ctypes.c_int32] + L.nlsh_scan_topk_phase.argtypes[8:]
     L.nlsh_merge_topk.restype = i32
     L.nlsh_merge_topk.argtypes = [vp, i64, i32, i64, i32, vp, vp, vp, vp, vp]
+    L.nlsh_step_create.restype = i32
+    L.nlsh_step_create.argtypes = [ctypes.POINTER(StepDesc), sz, ctypes.POINTER(vp)]
+    for name in ("nlsh_step_destroy", "nlsh_step_release", "nlsh_step_busy"):
+        getattr(L, name).restype = i32
+        getattr(L, name).argtypes = [vp]
+    L.nlsh_step_set_weights.restype = i32
+    L.nlsh_step_set_weights.argtypes = [vp, vp]
+    L.nlsh_query_step_enqueue.restype = i32
+    L.nlsh_query_step_enqueue.argtypes = [vp, vp, i64, u64, vp, vp, vp]
     _lib = L
     return L
 

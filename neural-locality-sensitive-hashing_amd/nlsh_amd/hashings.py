@@ -122,19 +122,27 @@ class MultivariateBernoulli:
         return [stack[0][0].shape[1]] + [w.shape[0] for w, _ in stack]
 
     def _weights_signature(self):
-        """(storage address, version counter) of every parameter and buffer of the hasher: changes whenever an optimiser step, a
-        `load_state_dict`, a `.cuda()` or a reassigned parameter changes what the packed blob was built from.  Called on every hashing
-        call, so it walks a cached list of the modules' own `_parameters` / `_buffers` dicts (a reassigned tensor is seen through the
-        dict) instead of `module.parameters()` -- the recursive module walk cost 30 us per call, a third of the host time of a pipelined
-        batch (r04, cProfile of `QueryPipeline.submit`).  Submodules ADDED after the first call are not seen: rebuild the hashing."""
+        """(name, storage address, version counter) of every parameter and buffer of the hasher: changes whenever an optimiser step, a
+        `load_state_dict`, a `.cuda()`, a reassigned or a newly registered parameter / buffer changes what the packed blob was built
+        from.  Called on every hashing call, so it walks a cached list of the modules' own `_parameters` / `_buffers` dicts (whatever
+        they hold NOW: `register_buffer`, `parametrize` or an assignment on an existing module is seen through the dict) instead of
+        `module.parameters()` -- the recursive module walk cost 30 us per call, a third of the host time of a pipelined batch (r04,
+        cProfile of `QueryPipeline.submit`).  The list itself is rebuilt when the module tree changed shape (a submodule added,
+        removed or swapped: the count and identities of the `_modules` entries are part of the cache key)."""
         cached = self.__dict__.get("_sig_slots")
+        if cached is not None and cached[0] is self._hasher:
+            for md, n, ids in cached[2]:                          # every module's child table: same length, same child objects
+                if len(md) != n or tuple(map(id, md.values())) != ids:
+                    cached = None
+                    break
         if cached is None or cached[0] is not self._hasher:           # a replaced `_hasher` module gets its own walk
-            cached = self._sig_slots = (self._hasher, [(d, name) for m in self._hasher.modules() for d in (m._parameters, m._buffers) for name in d])
-        slots = cached[1]
+            mods = list(self._hasher.modules())
+            cached = self._sig_slots = (self._hasher, [d for m in mods for d in (m._parameters, m._buffers)],
+                                        [(m._modules, len(m._modules), tuple(map(id, m._modules.values()))) for m in mods])
         sig = []
-        for d, name in slots:
-            t = d.get(name)
-            sig.append(None if t is None else (t.data_ptr(), t._version))
+        for d in cached[1]:
+            for name, t in d.items():
+                sig.append((name, None) if t is None else (name, t.data_ptr(), t._version))
         return tuple(sig)
 
     def packed_weights(self):

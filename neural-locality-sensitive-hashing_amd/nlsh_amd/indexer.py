@@ -382,16 +382,21 @@ class Indexer:
                 break
             needed, overflow = status.cpu().tolist()
             if not overflow:
-                # the one-shot tiled kernel launches a workgroup per table slot: a table sized for the bucket-per-task estimate and
-                # then run with shared windows (a fifth of the tasks) is trimmed once the batch shape's real need is known
-                if 3 * (needed + 1024) < max_tasks:
-                    self._max_tasks[tkey] = int(needed * 1.25) + 1024
+                self._trim_task_table(tkey, needed, max_tasks)
                 break
             self._grow_task_table(tkey, needed, overflow)           # segment table too small: grow and repeat
         self.last_status = status
         self.last_algo, self.last_window = algo, window
         self._last_pack, self._last_tkey, self._last_max_tasks = pack, tkey, max_tasks
         return out_dist, out_idx, ncand, out_keys
+
+    def _trim_task_table(self, tkey, needed, max_tasks):
+        """The one-shot tiled kernel launches a workgroup per table slot: a table sized for the bucket-per-task estimate and then
+        run with shared windows (a fifth of the tasks) is trimmed once the batch shape's real need is known.  Called wherever the
+        host learns `needed` anyway -- the checked scan, and `query()`'s own copy of the status words (the default
+        `query()` path never trimmed and kept launching mostly empty workgroups)."""
+        if 3 * (needed + 1024) < max_tasks:
+            self._max_tasks[tkey] = int(needed * 1.25) + 1024
 
     def _grow_task_table(self, tkey, needed, flag=1):
         """status[1] == 1: the task table was too small; grow it, the caller repeats the call.
@@ -497,6 +502,7 @@ class Indexer:
             host = pin.numpy()
             needed, overflow = int(host[n - 2]), int(host[n - 1])
             if not overflow or Q == 0:
+                self._trim_task_table(tkey, needed, self._last_max_tasks)
                 return (host[:Q * k].reshape(Q, k), host[Q * k:Q * k + Q], host[n:n + Q * P].reshape(Q, P), host[n + Q * P:n + nk])
             self._grow_task_table(tkey, needed, overflow)
 
@@ -540,7 +546,7 @@ class Indexer:
                 pin[base + n + m * P:base + n + m * P + m].copy_(nkeys[lo:hi], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(stream)
-            return ev, pack, tkey
+            return ev, pack, tkey, self._last_max_tasks
 
         for c, (lo, hi) in enumerate(bounds):
             inflight.append(launch(c, lo, hi))
@@ -549,11 +555,12 @@ class Indexer:
         for c, (lo, hi) in enumerate(bounds):
             m = hi - lo
             while True:
-                ev, pack, tkey = inflight[c]
+                ev, pack, tkey, max_tasks = inflight[c]
                 ev.synchronize()
                 base, n = c * words, pack.numel()
                 needed, overflow = int(host[base + n - 2]), int(host[base + n - 1])
                 if not overflow or m == 0:
+                    self._trim_task_table(tkey, needed, max_tasks)
                     break
                 self._grow_task_table(tkey, needed, overflow)       # task table too small for this range: grow, repeat it
                 inflight[c] = launch(c, lo, hi)

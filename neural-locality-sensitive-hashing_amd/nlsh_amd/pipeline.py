@@ -17,14 +17,19 @@ finished (event).  Results are bit-identical to `Indexer.query_tensors`: the ker
 same, only the stream they run on differs.  No reference counterpart (the reference answers one query at a time,
 nlsh/indexer.py:62-95).
 
-Buffer lifetimes: a submitted batch is read by all three streams after `submit` returns.  `submit` therefore marks the
-batch tensor as in use on the front, mid and tail streams (`record_stream`), so the caching allocator will not hand its
-memory to a later allocation until those streams have passed the batch -- the caller may drop the tensor at once, but
-must not OVERWRITE it in place before `synchronize()` (or the batch's results) say the batch is done.  The packed
-encoder weights are owned by the pipeline (a reference is held) and re-read from the hasher whenever its parameters
-changed since the last submit (a training step, `load_state`, a device move), so slots never keep a dangling pointer.
-A submit that raises leaves its slot's workspace in an undefined state (the PLAN phase keeps counters at its head zero
-between calls, include/nlsh_hip.h): build a new pipeline after an error.
+One C-ABI call per batch (r05, ABI v3): a slot is an `nlsh_step_t` of the library -- the validated encode launch, the scan call, the
+streams and the slot's events, built once -- and `submit` is ONE ctypes transition (`nlsh_query_step_enqueue`) that swaps in the batch
+pointer, its row stride and the Philox seed.  Through r04 `submit` issued the seven launches and ten event records / waits itself
+(~0.09 ms of host time per batch: at eight shards that WAS the step).
+
+Buffer lifetimes: a submitted batch is read by all stages after `submit` returns.  The pipeline keeps a reference to the batch tensor
+in the batch's slot, so the caller may drop it at once, but must not OVERWRITE it in place before `synchronize()` (or the batch's
+results) say the batch is done.  When the slot is reused while its previous batch is still in flight (the host running a whole
+pipeline depth ahead of the device), the old tensor is first marked as in use on the stage streams (`record_stream`), so the caching
+allocator will not hand its memory out until those streams have passed it.  The packed encoder weights are owned by the pipeline (a
+reference is held) and re-read from the hasher whenever its parameters changed since the last submit (a training step, `load_state`,
+a device move), so slots never keep a dangling pointer.  A submit that raises leaves its slot's workspace in an undefined state (the
+PLAN phase keeps counters at its head zero between calls, include/nlsh_hip.h): build a new pipeline after an error.
 """
 from typing import Callable, Optional
 
@@ -35,24 +40,6 @@ from . import _capi
 
 class _Slot:
     pass
-
-
-_hip = None
-
-
-def _hip_runtime():
-    """hipEventRecord / hipStreamWaitEvent on raw handles: a pipelined batch records and waits on ten events, and through
-    torch.cuda.Event each costs 3.5-4 us of host time (r04 cProfile: 37 of the ~90 us it takes to enqueue a batch, which at eight
-    shards is what bounds the step); the same two HIP calls through ctypes cost ~1 us."""
-    global _hip
-    if _hip is None:
-        import ctypes
-        _hip = ctypes.CDLL("libamdhip64.so")
-        _hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-        _hip.hipEventRecord.restype = ctypes.c_int
-        _hip.hipStreamWaitEvent.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
-        _hip.hipStreamWaitEvent.restype = ctypes.c_int
-    return _hip
 
 
 class QueryPipeline:
@@ -116,85 +103,108 @@ class QueryPipeline:
             s.ncand = torch.empty((self.Q,), dtype=torch.int32, device=dev)
             s.status = torch.zeros((2,), dtype=torch.int32, device=dev)
             s.ws = torch.zeros((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)   # PLAN-phase head must start out zero (include/nlsh_hip.h)
-            s.planned, s.scanned, s.done, s.encoded = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
-            for e in (s.planned, s.scanned, s.encoded, s.done):      # instantiate the hipEvent handles (torch creates them at the first record)
-                e.record(torch.cuda.current_stream(dev))
-            s.h_planned, s.h_scanned, s.h_encoded, s.h_done = s.planned.cuda_event, s.scanned.cuda_event, s.encoded.cuda_event, s.done.cuda_event
-            # everything about the slot's launches that does not change from batch to batch, as plain ints: a submit is
-            # four ctypes transitions + six event calls (built per call it cost 125 us of host time per batch, which
-            # is what bounded the pipeline on small shards)
-            s.scan_pre, s.scan_post = indexer._scan_args(self.Q, self.d, s.keys, s.nkeys, k, self.algo, self.max_tasks, s.out_dist,
-                                                         s.out_idx, s.out_keys, s.ncand, s.status, s.ws)
+            s.batch = None
+            s.step = None
             self.slots.append(s)
-        self._bind_weights()
         self._lib = _capi.lib()
-        self._hip = _hip_runtime()
         self._n_multi = indexer._n_multi_rows(self.Q)
+        self._hold_done = exchange is not None
+        self._packed = None
+        self._bind_weights()
         self.n_submitted = 0
         self.last_slot = None
 
+    def _make_step(self, s):
+        """The slot's `nlsh_step_t`: everything about its launches that does not change from batch to batch."""
+        import ctypes
+        ix, h = self.indexer, self.indexer._hashing
+        (n_layers, dims_arr, packed_ptr, act, key_mode, n_probes), _ = h.encode_args(self.P, s.keys, s.nkeys)
+        pre, post = ix._scan_args(self.Q, self.d, s.keys, s.nkeys, self.k, self.algo, self.max_tasks, s.out_dist, s.out_idx, s.out_keys,
+                                  s.ncand, s.status, s.ws)
+        (corpus, row_stride, d, gid, uniq, offsets, order, n_buckets, cell_of, cell_offsets, n_cells, inv_norm) = pre
+        (Q, qkeys, nkeys, P, k, metric, algo, seg, out_dist, out_idx, out_keys, ncand, status, ws, ws_bytes, max_tasks) = post
+        desc = _capi.StepDesc(
+            n_layers=n_layers, act=act, key_mode=key_mode, n_probes=n_probes, dims=ctypes.cast(dims_arr, ctypes.c_void_p), packed=packed_ptr,
+            n_multi_rows=self._n_multi, corpus_sorted=corpus, row_stride=row_stride, gid=gid, uniq_keys=uniq, offsets=offsets,
+            bucket_order=order, cell_of=cell_of, cell_offsets=cell_offsets, inv_norm=inv_norm, d=d, n_buckets=n_buckets, n_cells=n_cells,
+            k=k, metric=metric, algo=algo, seg_rows=seg, hold_done=int(self._hold_done), Q=Q, qkeys=qkeys, nkeys=nkeys, out_dist=out_dist,
+            out_idx=out_idx, out_keys=out_keys, out_ncand=ncand, status=status, workspace=ws, workspace_bytes=ws_bytes, max_tasks=max_tasks,
+            front=self.front.cuda_stream, plan=self.plan.cuda_stream if self.plan is not None else None, mid=self.mid.cuda_stream,
+            tail=self.tail.cuda_stream)
+        handle = ctypes.c_void_p()
+        _capi.check(self._lib.nlsh_step_create(ctypes.byref(desc), ctypes.sizeof(desc), ctypes.byref(handle)))
+        return handle
+
     def _bind_weights(self):
-        """(Re)build the fixed part of every slot's encode call from the hasher's CURRENT weights and keep the packed
-        blob alive for as long as the slots point at it."""
+        """Point every slot at the hasher's CURRENT packed weights and keep the blob alive for as long as the slots point at it."""
         h = self.indexer._hashing
-        self._packed = h.packed_weights()
-        self._packed.record_stream(self.front)      # read by encode_hash on the front stream, allocated on the caller's
+        packed = h.packed_weights()
+        packed.record_stream(self.front)      # read by encode_hash on the front stream, allocated on the caller's
         self._weights_sig = h._weights_signature()
         for s in self.slots:
-            s.enc_pre, s.enc_post = h.encode_args(self.P, s.keys, s.nkeys)
-            assert s.enc_pre[2] == self._packed.data_ptr()
+            if s.step is None:
+                self._packed = packed
+                s.step = self._make_step(s)
+            else:
+                _capi.check(self._lib.nlsh_step_set_weights(s.step, packed.data_ptr()))
+        self._packed = packed
+
+    def close(self):
+        """Destroy the slots' library objects (after the batches in flight have finished)."""
+        if getattr(self, "slots", None):
+            self.tail.synchronize()
+            for s in self.slots:
+                if s.step is not None:
+                    self._lib.nlsh_step_destroy(s.step)
+                    s.step = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown: the process is going away with the handles
+            pass
+
+    def _stage_streams(self):
+        return (self.front, self.mid, self.tail) + ((self.plan,) if self.plan is not None else ())
 
     def submit(self, queries, seed=None, events=None):
         """Enqueue one batch; returns (dist, idx, ncand, keys64 | None) -- device tensors owned by the batch's slot
         (or fresh ones from `exchange`), valid once the tail stream has passed the batch (`synchronize()`), and
         overwritten `depth` submits later.  `events`: (begin, end) pair recorded around the scan kernel.
-        The hasher's weights are the ones present at THIS call."""
+        The hasher's weights are the ones present at THIS call.  A batch that needs more tasks than the sample batch's table holds
+        (1.25x + 1024 of what the sample needed) is reported by `overflowed()`, not by this call: check it before trusting a result
+        of a batch much heavier than the sample."""
         if queries.shape != (self.Q, self.d) or queries.dtype != torch.float32 or queries.stride(1) != 1:
             raise ValueError("batch shape/dtype differs from the pipeline's sample batch")
-        if self.indexer._hashing._needs_train_forward():
+        ix, L = self.indexer, self._lib
+        if ix._hashing._needs_train_forward():
             # the pipeline launches the fused kernel on folded eval-mode weights; a BatchNorm encoder in train mode needs the module's
             # own batch-statistics forward (hashings._run_train_mode), which `Indexer.query` / `hash_device` route to
             raise _capi.NlshHipError(_capi.E_UNSUPPORTED, "pipelined batches need the hasher in eval mode (BatchNorm encoder in train "
                                                           "mode: call hashing.train_mode(False), or use Indexer.query)")
-        ix, L = self.indexer, self._lib
         s = self.slots[self.n_submitted % len(self.slots)]
         self.n_submitted += 1
-        front, mid, tail = self.front, self.mid, self.tail
         if ix._hashing._weights_signature() != self._weights_sig:
             if self.n_submitted > 1:
-                torch.cuda.current_stream(queries.device).wait_stream(front)   # batches in flight still read the old blob
+                torch.cuda.current_stream(queries.device).wait_stream(self.front)   # batches in flight still read the old blob
             self._bind_weights()
-        front.wait_stream(torch.cuda.current_stream(queries.device))        # the batch may still be in flight there
-        for st in (front, mid, tail) + ((self.plan,) if self.plan is not None else ()):   # every stage reads the batch tensor
-            queries.record_stream(st)
-        hip, hf, hm, ht = self._hip, front.cuda_stream, mid.cuda_stream, tail.cuda_stream
-        rc_ev = hip.hipStreamWaitEvent(hf, s.h_done, 0)                     # the slot's previous batch has left the tail
-        qp, qs = queries.data_ptr(), queries.stride(0)
+        if s.batch is not None and s.batch is not queries and L.nlsh_step_busy(s.step) != 0:
+            # the slot's previous batch is still in flight and its tensor is about to lose our reference: keep its memory away from
+            # the allocator until the stage streams have passed it (the host runs a pipeline depth ahead: the device-bound regime,
+            # where these calls cost nothing that matters)
+            for st in self._stage_streams():
+                s.batch.record_stream(st)
         if seed is None:
             seed = ix._hashing.next_seed()
-        rc = L.nlsh_encode_hash(qp, self.Q, qs, *s.enc_pre, self._n_multi, seed, 0, *s.enc_post, front.cuda_stream)
-        hp = hf
-        if self.plan is not None:
-            hp = self.plan.cuda_stream
-            rc_ev |= hip.hipEventRecord(s.h_encoded, hf) | hip.hipStreamWaitEvent(hp, s.h_encoded, 0)
-        if rc == 0:
-            rc = L.nlsh_scan_topk_cells_phase(*s.scan_pre, qp, qs, *s.scan_post, None, None, hp, _capi.PHASE_PLAN)
-        rc_ev |= hip.hipEventRecord(s.h_planned, hp) | hip.hipStreamWaitEvent(hm, s.h_planned, 0)
-        if rc == 0:
-            rc = L.nlsh_scan_topk_cells_phase(*s.scan_pre, qp, qs, *s.scan_post, events[0].cuda_event if events else None,
-                                        events[1].cuda_event if events else None, hm, _capi.PHASE_SCAN)
-        rc_ev |= hip.hipEventRecord(s.h_scanned, hm) | hip.hipStreamWaitEvent(ht, s.h_scanned, 0)
-        if rc == 0:
-            rc = L.nlsh_scan_topk_cells_phase(*s.scan_pre, qp, qs, *s.scan_post, None, None, ht, _capi.PHASE_MERGE)
+        rc = L.nlsh_query_step_enqueue(s.step, queries.data_ptr(), queries.stride(0), seed, torch.cuda.current_stream(queries.device).cuda_stream,
+                                       events[0].cuda_event if events else None, events[1].cuda_event if events else None)
+        s.batch = queries
         _capi.check(rc)
-        if rc_ev:
-            raise _capi.NlshHipError(_capi.E_HIP, f"hipEventRecord / hipStreamWaitEvent failed ({rc_ev})")
         out = (s.out_dist, s.out_idx, s.ncand, s.out_keys)
         if self.exchange is not None:
-            with torch.cuda.stream(tail):
+            with torch.cuda.stream(self.tail):
                 out = tuple(self.exchange(s.out_keys, s.ncand)) + (None,)
-        if hip.hipEventRecord(s.h_done, ht):
-            raise _capi.NlshHipError(_capi.E_HIP, "hipEventRecord failed")
+            _capi.check(L.nlsh_step_release(s.step))
         self.last_slot = s
         return out
 

@@ -122,6 +122,8 @@ def test_bench_gpus_2_self_launch_reports_two_ranks():
     assert len(lines) == 1
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["value"] > 0 and rec["device_resident_qps"] > 0
+    # the exchange as the data backend saw it: two ranks counted by an all-reduce of ones; ONE device on this rehearsal (a real node says 2)
+    assert rec["collective"] == {"backend": "gloo", "world_size_seen": 2, "distinct_devices": 1, "data_tensors_on": "cpu"}
     assert rec["scaling"] == "strong" and 0 <= rec["recall_at_10"] <= 1
     assert rec["roofline"]["frac"] <= 1.0 and rec["roofline"]["bound"] in ("valu", "hbm")
     assert "sharded x2" in rec["config"]["parallelism"]
@@ -129,7 +131,7 @@ def test_bench_gpus_2_self_launch_reports_two_ranks():
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + cmd[4:], env=env, capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-3000:]
     rec1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
-    assert rec1["n_gpus"] == 1 and rec1["recall_at_10"] == rec["recall_at_10"]
+    assert rec1["n_gpus"] == 1 and rec1["recall_at_10"] == rec["recall_at_10"] and rec1["collective"] is None
     assert rec1["config"]["mean_candidates_per_query"] == rec["config"]["mean_candidates_per_query"]
 
 
@@ -215,6 +217,7 @@ def test_bench_gpus_4_same_device_rehearsal(exchange):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 4 and rec["steps"] == 2 and rec["value"] > 0
     assert rec["own_slice_qps"] and rec["own_slice_qps"] > 0
+    assert rec["collective"]["world_size_seen"] == 4 and rec["collective"]["distinct_devices"] == 1 and rec["collective"]["backend"] == "gloo"
     assert rec["scaling_value_key"] == "device_resident_qps" and rec[rec["scaling_value_key"]] > 0
     assert "host-bound" in rec["value_protocol"] and "sharded x4" in rec["config"]["parallelism"]
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, env=_bench_env(), capture_output=True,

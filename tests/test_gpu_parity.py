@@ -74,8 +74,9 @@ def test_encode_hash_vs_oracle_and_reference(case):
 
 
 # the three forms of the encoder: <= 4096 rows 16-row workgroups of 16x16x4 tiles, <= 16384 rows 32-row workgroups on one LDS image,
-# beyond that the 128-row index-build form -- every one the same k-ascending fmaf chain as the oracle, at and around the switch-overs
-@pytest.mark.parametrize("n_rows", [1, 15, 16, 17, 63, 64, 65, 1000, 4096, 4097, 5000, 16384, 16385, 20001])
+# beyond that the 128-row index-build form -- every one the same k-ascending fmaf chain as the oracle, at and around the switch-overs and
+# around one / two workgroups per CU (8192 rows)
+@pytest.mark.parametrize("n_rows", [1, 15, 16, 17, 63, 64, 65, 1000, 4096, 4097, 5000, 8192, 8193, 8209, 10000, 12287, 12288, 12289, 16384, 16385, 20001])
 def test_encode_hash_ragged_sizes_bit_exact(n_rows):
     d, hidden, H = 128, (256, 256), 16
     Ws, bs = synth.make_weights([d] + list(hidden) + [H], seed=5)
@@ -95,6 +96,22 @@ def test_encode_hash_odd_architectures(dims):
     z, _, code = hashing.forward_device(dev(x))
     zo = oracle.mlp_forward(x, Ws, bs)
     assert np.array_equal(z.cpu().numpy().view(np.uint32), zo.view(np.uint32))
+
+
+def test_multiprobe_keys_of_the_headline_batch_shape_match_oracle_sampler():
+    """10^4 rows x 10 probes with the F6 rule (rows >= 8192 single-probe): the batch shape of the headline, 313 32-row workgroups
+    -- keys, key counts and first-occurrence order against the oracle's Philox sampler, row for row."""
+    d, hidden, H, n, rows = 128, (256, 256), 16, 10, 10_000
+    Ws, bs = synth.make_weights([d] + list(hidden) + [H], seed=11)
+    x, _, _ = synth.standardise(synth.sift_like(rows, d, seed=33))
+    hashing = make_hashing(d, hidden, H, Ws, bs)
+    _, probs, _ = hashing.forward_device(dev(x))
+    keys, nkeys = hashing.hash_device(dev(x), n=n, n_multi_rows=8192, seed=99)
+    ko, no = oracle.row_keys(probs.cpu().numpy(), n, "ref_int16", seed=99, n_multi_rows=8192)
+    kd, nd = keys.cpu().numpy().astype(np.int64), nkeys.cpu().numpy()
+    assert np.array_equal(nd, no) and np.all(no[8192:] == 1) and no[:8192].max() > 1
+    live = np.arange(n)[None, :] < no[:, None]
+    assert np.array_equal(kd[live], ko[live])
 
 
 def test_multiprobe_keys_match_oracle_sampler():

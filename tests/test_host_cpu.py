@@ -22,7 +22,7 @@ def test_capi_library_exports_every_declared_symbol():
     lib = _capi.lib()
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} not exported"
-    assert lib.nlsh_abi_version() == 2
+    assert lib.nlsh_abi_version() == 3
     # pure host-side argument validation (no device needed): errors come back as codes + message
     dims = _capi.int_array([128, 256, 256, 16])
     # the 32x32x2 fragments of every layer + biases, then (r04) the hidden layers once more packed for 16x16x4 tiles (the 16-row form)
@@ -31,6 +31,56 @@ def test_capi_library_exports_every_declared_symbol():
     assert b"hash_size" in lib.nlsh_last_error()
     assert lib.nlsh_encoder_packed_floats(2, _capi.int_array([128, 700, 16])) == -1       # 128 ok, 700 too wide
     assert lib.nlsh_scan_workspace(10, 4, 10, 100, 50, 128) > 0
+
+
+def test_step_descriptor_layout_and_host_side_validation():
+    """ABI v3: `_capi.StepDesc` mirrors `nlsh_step_desc_t` field for field (names and order checked against the header's text, the
+    size against the library, which refuses a descriptor of another size), and the host-side argument checks of the step calls
+    answer with codes + messages -- no device call is made for any of these."""
+    import ctypes
+    from nlsh_amd import _capi
+    header = open(os.path.join(ROOT, "include", "nlsh_hip.h")).read()
+    body = header[header.index("typedef struct nlsh_step_desc {"):header.index("} nlsh_step_desc_t;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if decl:
+            names += [re.sub(r"[\s*]", "", part).split(" ")[-1] for part in re.sub(r"^(const\s+)?[\w]+\s", "", decl, count=1).split(",")]
+    assert names == [f[0] for f in _capi.StepDesc._fields_], names
+    lib = _capi.lib()
+    desc, handle = _capi.StepDesc(), ctypes.c_void_p()
+    assert lib.nlsh_step_create(ctypes.byref(desc), ctypes.sizeof(desc) - 8, ctypes.byref(handle)) == _capi.E_INVALID
+    assert str(ctypes.sizeof(desc)).encode() in lib.nlsh_last_error()        # "... this library's is <sizeof>": the two layouts agree
+    assert lib.nlsh_step_create(ctypes.byref(desc), ctypes.sizeof(desc), ctypes.byref(handle)) == _capi.E_INVALID
+    assert b"streams" in lib.nlsh_last_error() and not handle.value
+    assert lib.nlsh_query_step_enqueue(None, None, 0, 0, None, None, None) == _capi.E_INVALID
+    assert lib.nlsh_step_busy(None) == _capi.E_INVALID and lib.nlsh_step_release(None) == _capi.E_INVALID
+    assert lib.nlsh_step_destroy(None) == _capi.OK
+
+
+def test_weights_signature_follows_the_module_as_it_is_now(monkeypatch):
+    """the cached walk behind `_weights_signature` (called per hashing call: `QueryPipeline.submit` re-binds the packed
+    weights when it changes) must see an in-place update, a parameter or buffer registered later, a swapped layer and an added submodule."""
+    monkeypatch.setattr(torch.nn.Module, "cuda", lambda self, *a, **k: self)      # no GPU here; the signature is host logic
+    from nlsh_amd.encoders import MultiLayerRelu
+    from nlsh_amd.hashings import MultivariateBernoulli
+    h = MultivariateBernoulli(MultiLayerRelu(8, [16, 16]), 4, None)
+    s0 = h._weights_signature()
+    assert s0 == h._weights_signature()
+    with torch.no_grad():
+        h._hasher.output_layer.weight.add_(1)
+    s1 = h._weights_signature()
+    assert s1 != s0
+    h._hasher.register_buffer("extra", torch.zeros(3))
+    s2 = h._weights_signature()
+    assert s2 != s1 and len(s2) == len(s1) + 1
+    enc = h._hasher._encoder
+    setattr(enc, list(enc._modules)[0], torch.nn.Linear(8, 16))
+    s3 = h._weights_signature()
+    assert s3 != s2 and len(s3) == len(s2)
+    enc.add_module("late", torch.nn.Linear(2, 2))
+    assert len(h._weights_signature()) == len(s3) + 2
 
 
 def test_product_never_references_the_oracle():

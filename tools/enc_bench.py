@@ -33,6 +33,10 @@ def timed(fn, n):
 
 big = timed(lambda: hashing.hash_device(x, n=1), 10)
 small = timed(lambda: hashing.hash_device(q, n=10, n_multi_rows=8192, seed=3), 200)
+by_rows = {}
+for rows in (4096, 8192, 8193, 9000, 10_000, 11_000, 12_288, 12_289, 16_384):   # the query-batch forms at and around their switch-overs
+    qr = x[:rows].contiguous()
+    by_rows[rows] = 1e3 * timed(lambda: hashing.hash_device(qr, n=10, n_multi_rows=(rows // 4096) * 4096, seed=3), 200)
 flops = 2.0 * (d * 256 + 256 * 256 + 256 * H)
 print(json.dumps({"tag": sys.argv[1] if len(sys.argv) > 1 else "", "rows_1M_ms": big, "mfma_util_1M": flops * 1e6 / (big * 1e-3) / 157.3e12,
-                  "queries_10k_us": small * 1e3}))
+                  "queries_10k_us": small * 1e3, "us_by_rows": by_rows}))
