@@ -122,6 +122,9 @@ struct BArgs {
     int2 *task_qr;     // tiled schedule: [max_tasks][16] {query id, row range lo | hi << 16} of every (task, slot): the task's group's slice of
                        // inv_q, repeated per row segment, and the rows of the query's bucket inside the task's rows (a whole segment of a
                        // big bucket; the bucket's slice of a shared window).  ONE 8-byte record: one store in bscatter, one load in the scan
+    int2 *task_hull;   // tiled schedule: [max_tasks] rows of the task that ANY of its queries owns, {first, one past the last} relative to the task's
+                       // first row: the whole task for a segment of a big bucket; for a window shared by several small buckets the hull of the
+                       // PROBED buckets' slices (bscatter: atomicMin / atomicMax) -- the scan stages and scores only those rows (r05)
     int32_t *pcell;    // [Q*P] cell of every (query, probe) pair's bucket (bplan looked it up for the counter: bscatter need not again)
     uint64_t *partial;
     long long max_tasks;
@@ -340,6 +343,8 @@ __global__ __launch_bounds__(256) void bscan_kernel(BArgs a, int plan_blocks) {
                 // at about the same time (and, with the chunked XCD map of bscan3, on one XCD's L2)
                 const int si = t / ng, gi = t - si * ng;
                 a.task[tt] = make_int4(po + gi * a.QB, min(a.QB, m - gi * a.QB), row0 + si * a.seg, min(a.seg, s - si * a.seg));
+                // one-segment cells under the small-bucket packing may hold unprobed buckets: their hull is gathered by bscatter
+                if (a.task_hull) a.task_hull[tt] = (ns == 1 && a.cell_of) ? make_int2(0x7FFFFFFF, 0) : make_int2(0, min(a.seg, s - si * a.seg));
             }
         }
     }
@@ -352,6 +357,7 @@ __global__ __launch_bounds__(256) void bscan_kernel(BArgs a, int plan_blocks) {
             if (tt >= a.max_tasks) break;
             const int si = t / hng, gi = t - si * hng;
             a.task[tt] = make_int4(po + gi * a.QB, min(a.QB, hm - gi * a.QB), row0 + si * a.seg, min(a.seg, hs - si * a.seg));
+            if (a.task_hull) a.task_hull[tt] = (hs <= a.seg && a.cell_of) ? make_int2(0x7FFFFFFF, 0) : make_int2(0, min(a.seg, hs - si * a.seg));
         }
     }
 }
@@ -390,6 +396,10 @@ __global__ __launch_bounds__(256) void bscatter_kernel(BArgs a) {
             if (tt >= a.max_tasks) break;
             const int lo = max(lo0 - si * a.seg, 0), hi = min(lo0 + size - si * a.seg, a.seg);   // the bucket's rows inside segment si
             a.task_qr[tt * a.QB + (rel - gi * a.QB)] = make_int2((int32_t)(idx / a.P), lo | (hi << 16));
+            if (a.cell_of && a.coffsets[c + 1] - a.coffsets[c] <= a.seg) {   // a one-segment cell (bscan_kernel left its hull open): widen it by this bucket's slice
+                atomicMin(&a.task_hull[tt].x, lo);
+                atomicMax(&a.task_hull[tt].y, hi);
+            }
         }
     }
 }
@@ -898,10 +908,63 @@ __device__ __forceinline__ void l2_task(float4 *tile, const float4 *corpus4, lon
     if (NQ > 0) warm_query_lines_done(qsink);
 }
 
+// Single-stage task (r05): a task whose rows x 16-byte chunks fit the workgroup's LDS stage at once (rows * d4 <= 1024 slots: <= 40 rows
+// of a 100-d corpus, <= 32 of a 128-d one) is staged in ONE pass -- four loads per thread over the rows' contiguous bytes, one barrier --
+// and scored by ONE k-block call over all d4 chunks.  The fat two-stage form it replaces for such tasks cut every row at byte 256: rows
+// of 400 bytes are not aligned to the 128-byte lines of the L2, so nearly every line held bytes of both stages and was requested twice,
+// a whole stage apart -- on the balanced workloads, whose scan is bound by the memory system (the load skeleton alone is 0.10 of GloVe's
+// 0.12 ms), the counters saw 1.33x the bytes the task table accounts for (profiles/r05_traffic_tally.txt).  Here every line of the task
+// is requested once, and the task has one exposed round trip less.  Same k-ascending fmaf chain per (row, query): same bits.
+#ifndef NLSH_SINGLE_STAGE
+#define NLSH_SINGLE_STAGE 1
+#endif
+constexpr int SINGLE_STAGE_SLOTS = 1024;   // float4 slots one pass of the 256 threads stages (4 each)
+template <int NW, int NQ, int METRIC = NLSH_METRIC_L2_EPS>
+__device__ __forceinline__ void l2_task_single(float4 *tile, const float4 *corpus4, long long stride4, int d4, int row0, int nrows,
+                                               const const_f32p (&qs)[4], int tid, int lane, float (&acc)[4][4]) {
+    constexpr int NTH = 64 * NW, SPT = SINGLE_STAGE_SLOTS / NTH;
+    const int RS = d4 | 1;                   // odd LDS row stride (16-byte slots): conflict-free column reads
+    const int total = nrows * d4;
+    const float inv = 1.0f / (float)d4;
+    // (r05: the pass started at the 128-byte line below the task's first byte, so that every wave-load covered whole lines of the L2: the
+    // counters did not move -- 289.6 against 289.5 K FETCH_SIZE units per GloVe launch -- and the shift was removed; DESIGN.md appendix A.)
+    float4 stg[SPT];
+    int dst[SPT];
+#pragma unroll
+    for (int i = 0; i < SPT; ++i) {
+        const int idx = min(tid + NTH * i, total - 1);   // slots past the task's last chunk re-read it (valid address, value never written)
+        int r = (int)((float)idx * inv);                  // idx / d4 without an integer division: off by at most one, put right below
+        r -= (r * d4 > idx) ? 1 : 0;
+        r += ((r + 1) * d4 <= idx) ? 1 : 0;
+        const int c = idx - r * d4;
+        stg[i] = (NLSH_ABLATE != 2 && NLSH_ABLATE != 12 && NLSH_ABLATE != 13) ? corpus4[(long long)(row0 + r) * stride4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        dst[i] = r * RS + c;
+    }
+    float qsink = 0.0f;
+    asm volatile("" : "+s"(qsink));
+    if (NQ > 0) warm_query_lines<(NQ > 0 ? NQ : 1)>(qs, 0, d4 * 16, qsink);
+    // one task per workgroup: nobody has read the tile before, so the writes need no barrier in front of them
+#pragma unroll
+    for (int i = 0; i < SPT; ++i)
+        if (tid + NTH * i < total) tile[dst[i]] = stg[i];
+    NLSH_STAGE_SYNC();
+    if (NQ > 0) {
+        warm_query_lines_done(qsink);
+        if (NLSH_ABLATE != 1 && NLSH_ABLATE != 6 && NLSH_ABLATE != 13) {
+            const_f32p qk[4];
+#pragma unroll
+            for (int jq = 0; jq < 4; ++jq) qk[jq] = qs[jq];
+            // lanes past the task's last row walk its last row (staged data; their results are masked at the epilogue)
+            l2_kblock<(NQ > 0 ? NQ : 1), 1, METRIC>(tile + min(lane, nrows - 1) * RS, RS, d4, qk, acc);
+        }
+    }
+}
+
 template <int NW, int NQ, int METRIC = NLSH_METRIC_L2_EPS>
 __device__ __forceinline__ void l2_task_nt(int ntile, float4 *tile, const float4 *corpus4, long long stride4, int d4, int row0, int nrows,
                                            const const_f32p (&qs)[4], int tid, int lane, float (&acc)[4][4], unsigned long long (&tr)[3]) {
     switch (ntile) {
+        case 0: l2_task_single<NW, NQ, METRIC>(tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc); break;   // "0 tiles": the single-stage body
         case 1: l2_task<NW, NQ, 1, METRIC>(tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, tr); break;
         case 2: l2_task<NW, NQ, 2, METRIC>(tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, tr); break;
         case 3: l2_task<NW, NQ, 3, METRIC>(tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, tr); break;
@@ -977,7 +1040,7 @@ __device__ __forceinline__ void merge_query(const BArgs &a, long long q, int lan
 // One task of the tiled schedule, start to finish (operands of the task already requested by the caller: descriptor and
 // the wave's query ids).  `tile` = the workgroup's LDS stage.
 template <int METRIC, int QW, int NW, int TPS>
-__device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, long long t, const int4 desc, const int (&qid_v)[QW], const int (&rng_v)[QW], int tid, int lane,
+__device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, long long t, const int4 desc, const int2 hull, const int (&qid_v)[QW], const int (&rng_v)[QW], int tid, int lane,
                                                 int wave, [[maybe_unused]] unsigned long long ts_entry) {
     constexpr int NT = 64 * NW;              // threads per workgroup
     constexpr int KB = NLSH_TILED_KB;        // 16-byte chunks per k-block
@@ -990,8 +1053,14 @@ __device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, lo
     const unsigned long long core0 = __builtin_amdgcn_s_memtime();   // shader-clock counter beside the 100 MHz stamps: the clock held
 #endif
     const int nq = __builtin_amdgcn_readfirstlane(desc.y);       // desc.x (first pair of the group) is the wave-level schedule's: the tiled tasks carry their query ids
-    const int row0 = __builtin_amdgcn_readfirstlane(desc.z);
-    const int nrows = __builtin_amdgcn_readfirstlane(desc.w);  // <= ROWS (the host fixes seg = ROWS)
+    // The task's rows, narrowed to the hull of the rows its queries own: a 64-row window shared by several small buckets is staged and
+    // scored from the first row of its first PROBED bucket to the last row of its last one (GloVe-1.2M: 1.27x -> 1.10x the rows of the
+    // probed buckets, profiles/r05_traffic_tally.txt; the balanced workloads' scan is bound by the bytes it moves).  Same rows per query,
+    // same chains: same bits.
+    const int h_lo = __builtin_amdgcn_readfirstlane(hull.x);
+    const int row0 = __builtin_amdgcn_readfirstlane(desc.z) + h_lo;
+    const int nrows = min(__builtin_amdgcn_readfirstlane(hull.y), __builtin_amdgcn_readfirstlane(desc.w)) - h_lo;  // <= ROWS (the host fixes seg = ROWS)
+    if (nrows <= 0) return;   // wave-uniform, in front of every barrier: a task nobody wrote a slot of (cannot happen while the contract holds)
     // queries are dealt round-robin over the waves (slot = wave + NW*jq): a group of 5 queries costs the
     // workgroup 2 query-times per stage (2,1,1,1) instead of 4 (4,1,0,0); the stage barrier waits for the slowest wave
     int nqw = NLSH_DEAL_BLOCKS ? nq - wave * QW : (nq - wave + NW - 1) / NW;
@@ -1053,13 +1122,15 @@ __device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, lo
     constexpr bool FAST = NLSH_FAST_KBLOCK && (METRIC != NLSH_METRIC_COSINE || NLSH_FAST_COSINE) && QW == 4 && TPS == 4;
     [[maybe_unused]] unsigned long long trl[3] = {0, 0, 0};
     [[maybe_unused]] const unsigned long long ts_in = SCAN_NOW();
+    // a task whose rows x chunks fit one stage takes the single-stage body (l2_task_single): selected as "0 tiles" of the same switch
+    const int nt_sel = (NLSH_SINGLE_STAGE && nrows * d4 <= SINGLE_STAGE_SLOTS && nrows <= 64) ? 0 : ntile;   // wave-uniform (task shape)
     if (FAST) {   // hand-scheduled form, specialised per (queries of this wave, tiles of the task); same barrier count on every path
         switch (nqw) {
-            case 0: l2_task_nt<NW, 0, METRIC>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
-            case 1: l2_task_nt<NW, 1, METRIC>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
-            case 2: l2_task_nt<NW, 2, METRIC>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
-            case 3: l2_task_nt<NW, 3, METRIC>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
-            default: l2_task_nt<NW, 4, METRIC>(ntile, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
+            case 0: l2_task_nt<NW, 0, METRIC>(nt_sel, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
+            case 1: l2_task_nt<NW, 1, METRIC>(nt_sel, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
+            case 2: l2_task_nt<NW, 2, METRIC>(nt_sel, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
+            case 3: l2_task_nt<NW, 3, METRIC>(nt_sel, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
+            default: l2_task_nt<NW, 4, METRIC>(nt_sel, tile, corpus4, stride4, d4, row0, nrows, qs, tid, lane, acc, trl); break;
         }
     }
     if (!FAST) stage_load(0);
@@ -1135,18 +1206,15 @@ __device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, lo
             // window shared by several small buckets (the other rows were scored for nothing: the arithmetic of a shared window is what
             // a task of its own would have cost each of those buckets in fixed latency)
             const int rng = __builtin_amdgcn_readfirstlane(rng_v[jq]);
-            const unsigned r_lo = (unsigned)(rng & 0xFFFF), r_n = (unsigned)(rng >> 16) - r_lo;
+            const unsigned r_lo = (unsigned)((rng & 0xFFFF) - h_lo), r_n = (unsigned)(rng >> 16) - (unsigned)(rng & 0xFFFF);   // relative to the first row staged
             uint64_t key[TPS];
             // LEAN: every accumulator of the list at or above 2^-96 (wave-uniform test; NaN compares false and takes the general path)
             // -> square roots without the range scaling, and a non-negative distance's order-preserving word is its bits with the sign set
             bool lean = LEAN;
-            if (LEAN) {
-                float lo4 = acc[0][jq];
+            if (LEAN) {   // tiles the task does not have hold zeros and lanes past its last row another row's (or nobody's) sums: neither is asked
+                bool ok = true;
 #pragma unroll
-                for (int tl = 1; tl < TPS; ++tl) lo4 = fminf(lo4, acc[tl][jq]);
-                bool ok = lo4 >= 0x1p-96f;
-#pragma unroll
-                for (int tl = 0; tl < TPS; ++tl) ok = ok && acc[tl][jq] == acc[tl][jq];   // fminf drops a NaN operand: ask every one
+                for (int tl = 0; tl < TPS; ++tl) ok = ok && (tl >= ntile || !valid[tl] || acc[tl][jq] >= 0x1p-96f);   // a NaN fails the comparison
                 lean = __ballot(!ok) == 0ull;
             }
 #pragma unroll
@@ -1232,6 +1300,7 @@ __global__ __launch_bounds__(64 * NW, NLSH_TILED_MIN_WAVES) void bscan3_kernel(B
     // less in front of every task
     const long long tc = t < a.max_tasks ? t : a.max_tasks - 1;
     const int4 desc = a.task[tc];
+    const int2 hull = a.task_hull[tc];                // rows of the task its queries own at all (r05): requested with the descriptor
     int qid_v[QW], rng_v[QW];                         // the task's query ids and each query's row range inside the task's rows: address known from the task id alone
 #pragma unroll
     for (int jq = 0; jq < QW; ++jq) {   // slots >= nq hold garbage, never used; ids clamped into [0, Q) so that a slot a stale counter invented (bmerge flags it) addresses nothing outside the queries
@@ -1243,7 +1312,7 @@ __global__ __launch_bounds__(64 * NW, NLSH_TILED_MIN_WAVES) void bscan3_kernel(B
     if (NLSH_ABLATE == 9) return;   // diagnostic: every workgroup leaves after its descriptor loads (what dispatching the grid costs)
     if (NLSH_ABLATE == 8 && desc.y <= NLSH_ABLATE_NQ) return;   // diagnostic: tasks with few queries vanish (what the low-density tasks cost)
     if (NLSH_ABLATE == 7 && desc.w <= 64) return;   // diagnostic: tasks of <= 64 rows vanish (what a kernel without the tail of tiny tasks would take)
-    tiled_task_body<METRIC, QW, NW, TPS>(a, tile, t, desc, qid_v, rng_v, tid, lane, wave, ts_entry);
+    tiled_task_body<METRIC, QW, NW, TPS>(a, tile, t, desc, hull, qid_v, rng_v, tid, lane, wave, ts_entry);
 }
 
 __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
@@ -1270,9 +1339,12 @@ constexpr int TILED_QB = NLSH_TILED_QB;  // queries per task of the tiled schedu
 #define NLSH_TILED_TPS 4
 #endif
 constexpr int TILED_TPS = NLSH_TILED_TPS;  // 64-row tiles per task of the tiled schedule (segment = 64*TPS rows)
+// a shared window (nlsh_build_cells: window_rows <= 256) must fit ONE segment: bscatter derives a window bucket's partial-list count from
+// its own size and clamps its row range to the segment, so a window wider than a segment would silently lose rows
+static_assert(64 * TILED_TPS >= 256, "the tiled schedule's segment must hold the widest row window nlsh_build_cells accepts (256 rows)");
 
 struct BWs {
-    size_t pbkt, prec, inv_q, bcount, pairoff, taskoff, bgroups, counters, btot, hits, task, task_qr, pcell, partial, qpad, tauq, total;
+    size_t pbkt, prec, inv_q, bcount, pairoff, taskoff, bgroups, counters, btot, hits, task, task_qr, task_hull, pcell, partial, qpad, tauq, total;
 };
 static void blayout(long long Q, int P, int k, long long max_tasks, long long nb, int d, bool tiled, BWs *w) {
     size_t o = 0;
@@ -1289,6 +1361,7 @@ static void blayout(long long Q, int P, int k, long long max_tasks, long long nb
     w->hits = o;     o += ws_align((size_t)((Q * P + 255) / 256 + 1) * 4);
     w->task = o;     o += ws_align((size_t)max_tasks * sizeof(int4));
     w->task_qr = o;  o += tiled ? ws_align((size_t)max_tasks * TILED_QB * 8) : 0;
+    w->task_hull = o; o += tiled ? ws_align((size_t)max_tasks * 8) : 0;
     w->pcell = o;    o += ws_align(qp);
     w->partial = o;  o += ws_align((size_t)max_tasks * (tiled ? TILED_QB : 8) * k * 8);
     w->qpad = o;     o += tiled ? ws_align((size_t)Q * ((d + 3) / 4) * 16) : 0;
@@ -1351,7 +1424,7 @@ int bucket_scan_run(const BucketScanCall &c) {
     char *base = (char *)c.workspace;
     a.pbkt = (int32_t *)(base + w.pbkt); a.prec = (int4 *)(base + w.prec); a.inv_q = (int32_t *)(base + w.inv_q);
     a.bcount = (int32_t *)(base + w.bcount); a.pairoff = (int32_t *)(base + w.pairoff); a.taskoff = (int32_t *)(base + w.taskoff); a.bgroups = (int32_t *)(base + w.bgroups);
-    a.counters = (int32_t *)(base + w.counters); a.btot = (int32_t *)(base + w.btot); a.hits = (int32_t *)(base + w.hits); a.border = c.bucket_order; a.task = (int4 *)(base + w.task); a.task_qr = c.tiled ? (int2 *)(base + w.task_qr) : nullptr; a.pcell = (int32_t *)(base + w.pcell); a.partial = (uint64_t *)(base + w.partial);
+    a.counters = (int32_t *)(base + w.counters); a.btot = (int32_t *)(base + w.btot); a.hits = (int32_t *)(base + w.hits); a.border = c.bucket_order; a.task = (int4 *)(base + w.task); a.task_qr = c.tiled ? (int2 *)(base + w.task_qr) : nullptr; a.task_hull = c.tiled ? (int2 *)(base + w.task_hull) : nullptr; a.pcell = (int32_t *)(base + w.pcell); a.partial = (uint64_t *)(base + w.partial);
     a.max_tasks = c.max_tasks;
     a.tauq = (unsigned long long *)(base + w.tauq);
 

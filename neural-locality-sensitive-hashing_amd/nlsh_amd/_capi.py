@@ -58,8 +58,13 @@ class StepDesc(ctypes.Structure):
 
 
 def build_library(force=False):
-    """Compile csrc/*.hip for gfx950 (hipcc cross-compiles without a GPU)."""
+    """Compile csrc/*.hip for gfx950 (hipcc cross-compiles without a GPU).  The optional list-construction helper is built for THIS
+    interpreter (extension suffix and include directory from sysconfig), not for whichever python3-config is on PATH."""
+    import sysconfig
     args = ["make", "-C", CSRC, "-j4"]
+    suffix, inc = sysconfig.get_config_var("EXT_SUFFIX"), sysconfig.get_paths().get("include")
+    if suffix and inc and os.path.exists(os.path.join(inc, "Python.h")):
+        args += [f"PYSUFFIX={suffix}", f"PYINCLUDES=-I{inc}"]
     if force:
         subprocess.check_call(["make", "-C", CSRC, "clean"])
     subprocess.check_call(args)

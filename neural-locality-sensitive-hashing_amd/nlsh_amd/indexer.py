@@ -110,7 +110,8 @@ class Indexer:
     def __init__(self, hashing, candidate_vectors_gpu, distance_func, compat=True, metric: Optional[str] = None,
                  seg_rows: int = 0, id_base: int = 0, algo: Optional[str] = None,
                  row_ids: Optional[torch.Tensor] = None, schedule_stats: Optional[Tuple[float, float]] = None,
-                 corpus_keys: Optional[torch.Tensor] = None, l2_form: str = "exact", window_rows: Optional[int] = None):
+                 corpus_keys: Optional[torch.Tensor] = None, l2_form: str = "exact", window_rows: Optional[int] = None,
+                 row_align: int = 4):
         self._hashing = hashing
         self._candidate_vectors_gpu = candidate_vectors_gpu
         self._distance_func = distance_func
@@ -141,6 +142,12 @@ class Indexer:
         if window_rows is not None and not 0 <= int(window_rows) <= 256:
             raise ValueError("window_rows must be None (auto) or in [0, 256]")
         self.window_rows = None if window_rows is None else int(window_rows)
+        # Row stride of the bucket-sorted corpus copy, in floats: ceil(d / row_align) * row_align.  4 (default) packs rows at 16-byte
+        # granularity; 32 starts every row on a 128-byte line of the L2 at the price of padding (100-d: 400 -> 512 bytes per row).
+        # Never changes a result (padding columns are never read: the kernels walk d, not the stride).
+        if row_align % 4 or row_align < 4:
+            raise ValueError("row_align must be a multiple of 4 floats")
+        self.row_align = int(row_align)
         self._cells = {}            # window_rows -> (cell_of, cell_offsets, cell_order, n_cells), built on first use
         self._index2row = None
         self._perm_host = None
@@ -170,7 +177,8 @@ class Indexer:
         self.perm, self.uniq_keys, self.offsets = build_csr_device(self.corpus_keys)
         self.n_buckets = int(self.uniq_keys.shape[0])
         self.dim = d
-        self.row_stride = (d + 3) // 4 * 4
+        align = max(4, int(self.row_align))       # floats; 4 = 16-byte rows (the default), 32 = every row starts on a 128-byte line
+        self.row_stride = (d + align - 1) // align * align
         dev = corpus.device
         self.corpus_sorted = torch.empty((N, self.row_stride), dtype=torch.float32, device=dev)
         self.gid = torch.empty((N,), dtype=torch.int32, device=dev)
@@ -649,10 +657,25 @@ class Indexer:
             self._held = []
         return result
 
+    # The cyclic collector is paused for the length of a `query()` call, not only while a row range is converted: with tracked rows
+    # (the default) every resume between two ranges is followed by a young-generation pass over the lists made so far, and every tenth
+    # young pass by an older-generation one over all the tracked lists alive -- the collector's work per call grew with the number of row
+    # ranges (r04, tools/query_modes.py, same box: 1 range 1.47 ms per call, 2 ranges 1.93, 4 ranges 2.66), which is what kept the split
+    # from paying.  Paused across the call the fresh lists are walked once, after the call, whatever the split.  No generation is
+    # rewritten and nothing is frozen (unlike `promote_results`): the collector simply does not run inside the call, as it already did
+    # not inside the conversions.  False restores r04's behaviour (tools/query_modes.py times both).
+    pause_collector_for_call = True
+
     def query(self, query_vectors, k=10, hash_times=10, seed=None) -> Tuple[List[List[int]], List[int]]:
         """nlsh/indexer.py:56-96.  `seed` (not in the reference): the Philox seed of the multi-probe draws; None takes the next one
         from the hasher's call counter, like every other hashing call."""
-        return self._keep(self._query(query_vectors, k, hash_times, seed))
+        if not (self.pause_collector_for_call and gc.isenabled()):
+            return self._keep(self._query(query_vectors, k, hash_times, seed))
+        gc.disable()
+        try:
+            return self._keep(self._query(query_vectors, k, hash_times, seed))
+        finally:
+            gc.enable()
 
     def _query(self, query_vectors, k, hash_times, seed):
         if self.metric not in ("l2", "cosine"):

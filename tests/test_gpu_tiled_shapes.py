@@ -15,7 +15,7 @@ from oracle import oracle
 
 pytestmark = pytest.mark.gpu
 
-SIZES = (1, 40, 64, 65, 100, 128, 150, 192, 230, 256, 300, 513)     # rows per bucket: 1..4 tiles, 2- and 3-segment buckets
+SIZES = (1, 20, 40, 64, 65, 100, 128, 150, 192, 230, 256, 300, 513)  # rows per bucket: single-stage tasks (20 rows; 40 up to 100-d), 1..4 tiles, 2- and 3-segment buckets
 GROUPS = tuple(range(1, 17)) + (17, 21, 33)                          # queries probing a bucket: every nq 1..16, and > 16 (several groups)
 Q = 64
 
@@ -85,6 +85,15 @@ def test_every_tiled_task_body_matches_the_oracle(metric, d):
         for wave in range(4):                                       # queries are dealt round-robin over the 4 waves (NLSH_SLOT)
             shapes.add((max(0, min(4, (a - wave + 3) // 4)), nt))
     assert shapes == {(q_, t_) for q_ in range(5) for t_ in range(1, 5)}, sorted(shapes)
+    # one-tile tasks come in two forms (r05): the whole task in ONE stage when rows x 16-byte chunks fit 1024 slots (l2_task_single), the
+    # fat two-stage form otherwise -- both present for every number of queries a wave can hold
+    d4 = (d + 3) // 4
+    for one_stage in (True, False):
+        got = set()
+        for a, r in zip(nq.tolist(), nrows.tolist()):
+            if r <= 64 and (r * d4 <= 1024) == one_stage:
+                got |= {max(0, min(4, (a - wave + 3) // 4)) for wave in range(4)}
+        assert got == set(range(5)), (one_stage, sorted(got))
     assert {(a, (r + 63) // 64) for a, r in zip(nq.tolist(), nrows.tolist())} >= {(a, t) for a in range(1, 17) for t in range(1, 5)}
     # expected task count: per bucket ceil(m / 16) query groups x ceil(size / 256) segments
     assert len(nq) == sum(((m + 15) // 16) * ((s + 255) // 256) for s, m in buckets)

@@ -316,6 +316,37 @@ def test_deferred_result_release_is_opt_in_and_drops_the_older_result_under_the_
         Indexer.defer_result_release = False
 
 
+def test_query_pauses_the_collector_for_the_call_and_leaves_it_as_it_found_it(monkeypatch):
+    """r05: `Indexer.query` runs with the cyclic collector paused from entry to exit (not only inside each row range's conversion), so
+    that the fresh result lists are walked once, after the call, whatever the row-range split.  The application's collector state is
+    restored on every path: enabled stays enabled (also when the call raises), disabled stays disabled, and the switch turns it off."""
+    import gc
+    from nlsh_amd.indexer import Indexer
+    ix = Indexer.__new__(Indexer)                      # host logic only: no index, no device
+    seen = []
+
+    def fake_query(self, q, k, hash_times, seed):
+        seen.append(gc.isenabled())
+        if q == "boom":
+            raise RuntimeError("boom")
+        return [[1]], [1]
+    monkeypatch.setattr(Indexer, "_query", fake_query)
+    assert gc.isenabled()
+    assert ix.query("x") == ([[1]], [1]) and seen == [False] and gc.isenabled()
+    with pytest.raises(RuntimeError):
+        ix.query("boom")
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        ix.query("x")
+        assert not gc.isenabled() and seen[-1] is False
+    finally:
+        gc.enable()
+    monkeypatch.setattr(Indexer, "pause_collector_for_call", False)
+    ix.query("x")
+    assert seen[-1] is True and gc.isenabled()
+
+
 def test_fastlists_builds_the_same_lists_as_ndarray_tolist():
     """csrc/fastlists.c: the host-side list builder of `Indexer._plain_lists` is `ndarray.tolist()` element for element (types too),
     refuses a short buffer, and is what the facade uses when it is built."""

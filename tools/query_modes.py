@@ -25,9 +25,10 @@ qb = [torch.from_numpy(synth.standardise(synth.sift_manifold(Q, d, seed=synth.SE
 fast = ixmod._rows_to_lists
 
 
-def run(builder, promote, defer, chunks, untrack=False, n=60):
+def run(builder, promote, defer, chunks, untrack=False, n=60, pause=True):
     ixmod._rows_to_lists = builder
     Indexer.promote_results, Indexer.defer_result_release, Indexer.query_chunks, Indexer.untracked_results = promote, defer, chunks, untrack
+    Indexer.pause_collector_for_call = pause
     keep = None
     for i in range(8):
         keep = ix.query(qb[i % 4], 10, 10)
@@ -40,19 +41,24 @@ def run(builder, promote, defer, chunks, untrack=False, n=60):
 
 
 rows = []
-for rep in range(2):
-    for name, builder, promote, defer, chunks, untrack in (
-            ("tolist, defaults (2 ranges)", None, False, False, None, False),
-            ("fastlists, defaults (tracked rows, 2 ranges)", fast, False, False, None, False),
-            ("fastlists, defaults, 1 range", fast, False, False, 1, False),
-            ("fastlists, defaults, 3 ranges", fast, False, False, 3, False),
-            ("fastlists, defaults, 4 ranges", fast, False, False, 4, False),
-            ("fastlists + untracked rows", fast, False, False, None, True),
-            ("fastlists + defer", fast, False, True, None, False),
-            ("fastlists + untracked + defer (bench.py's opt-in region)", fast, False, True, None, True),
-            ("fastlists + untracked + promote + defer", fast, True, True, None, True)):
+for rep in range(3):
+    for name, builder, promote, defer, chunks, untrack, pause in (
+            ("tolist, r04 defaults (2 ranges, collector paused per range)", None, False, False, 2, False, False),
+            ("fastlists, r04 defaults (tracked rows, 2 ranges, paused per range)", fast, False, False, 2, False, False),
+            ("fastlists, 1 range, paused per range", fast, False, False, 1, False, False),
+            ("fastlists, 4 ranges, paused per range", fast, False, False, 4, False, False),
+            ("fastlists, 1 range, collector paused for the call", fast, False, False, 1, False, True),
+            ("fastlists, 2 ranges, collector paused for the call", fast, False, False, 2, False, True),
+            ("fastlists, 3 ranges, collector paused for the call", fast, False, False, 3, False, True),
+            ("fastlists, 4 ranges, collector paused for the call", fast, False, False, 4, False, True),
+            ("fastlists, r05 defaults (automatic ranges, paused for the call)", fast, False, False, None, False, True),
+            ("fastlists + untracked rows", fast, False, False, None, True, True),
+            ("fastlists + defer", fast, False, True, None, False, True),
+            ("fastlists + untracked + defer (bench.py's opt-in region)", fast, False, True, None, True, True),
+            ("fastlists + untracked + promote + defer", fast, True, True, None, True, True)):
         if builder is None or fast is not None:
-            rows.append((name, round(run(builder, promote, defer, chunks, untrack), 4)))
+            rows.append((name, round(run(builder, promote, defer, chunks, untrack, pause=pause), 4)))
 Indexer.promote_results, Indexer.defer_result_release, Indexer.query_chunks, Indexer.untracked_results = False, False, None, False
+Indexer.pause_collector_for_call = True
 ixmod._rows_to_lists = fast
 print(json.dumps(rows))

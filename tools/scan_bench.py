@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--l2-form", default="exact", choices=["exact", "folded"], help="folded: the opt-in 2-op L2 block (NLSH_METRIC_L2_EPS_FOLDED)")
     ap.add_argument("--stress", type=int, default=0, help="repeat the scan N more times and count results that differ from the first one in any bit (the tiled schedule's results do not depend on timing: any difference is a race)")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--row-align", type=int, default=4, help="row stride of the sorted corpus copy = ceil(d / A) * A floats (32: every row starts on a 128-byte line)")
     ap.add_argument("--zeros", action="store_true", help="zero the grouped corpus and the queries after the index and the keys exist: same tasks and instruction stream, operands that toggle nothing (DVFS probe; pair with -DNLSH_ABLATE=5, ties change the selection)")
     ap.add_argument("--order", default="", choices=["", "pairs", "work", "density"], help="experiment: schedule order of the buckets recomputed on the host from THIS batch's keys (pairs: by (query, probe) pairs hitting the bucket; work: pairs x rows; density: full 16-query groups first, then by pairs), in place of the static size order")
     ap.add_argument("--tight", type=float, default=0.0, help="task table (= grid of the one-shot scan kernel) set to TIGHT x the tasks the batch needs (experiment; 0: the facade's estimate)")
@@ -57,7 +58,7 @@ def main():
     cg, qg = torch.from_numpy(corpus_h).cuda(), torch.from_numpy(queries_h).cuda()
     if args.metric:
         dist_fn = SIFT.distance if args.metric == "l2" else Glove.distance
-    ix = Indexer(hashing, cg, dist_fn, compat=compat, algo=args.algo, l2_form=args.l2_form)
+    ix = Indexer(hashing, cg, dist_fn, compat=compat, algo=args.algo, l2_form=args.l2_form, row_align=args.row_align)
     keys, nkeys = ix.hash_device(qg, hash_times=10, seed=7)
     if args.order:
         uk = ix.uniq_keys.cpu().numpy().astype(np.int64)
@@ -137,7 +138,7 @@ def main():
             rec["ids_equal_frac"] = float((i0 == idx).all(1).float().mean())
             both = (i0 >= 0) & (idx >= 0)
             rec["max_abs_dist_diff"] = float((d0 - dist).abs()[both].max())
-        rec["window_rows"], rec["workload"] = ix.last_window, args.workload
+        rec["window_rows"], rec["workload"], rec["row_stride"] = ix.last_window, args.workload, ix.row_stride
         rec["pairs"], rec["probed_buckets"], rec["unique_probed_rows"], rec["unique_probed_bytes"] = n_pairs, int(len(probed_)), unique_rows, unique_rows * 4 * ix.dim
         by_window.setdefault(ix.last_window, []).append(rec["scan_kernel_ms"])
         if window:

@@ -59,11 +59,23 @@ def main():
     ix.scan_tensors(q, keys, nkeys, k=10)          # second call: the trimmed task table
     torch.cuda.synchronize()
     n_tasks, max_tasks = int(ix.last_status.cpu()[0]), ix._last_max_tasks
-    off = ctypes.c_size_t()
-    _capi.check(_capi.lib().nlsh_scan_workspace_layout(Q, keys.shape[1], 10, max_tasks, ix.n_buckets, d, _capi.SCAN_BUCKET_TILED, ctypes.byref(off), None, None))
+    off, off_q = ctypes.c_size_t(), ctypes.c_size_t()
+    _capi.check(_capi.lib().nlsh_scan_workspace_layout(Q, keys.shape[1], 10, max_tasks, ix.n_buckets, d, _capi.SCAN_BUCKET_TILED, ctypes.byref(off), ctypes.byref(off_q), None))
     ws = next(w for (s_, bm), w in ix._ws.items() if bm)
     tasks = ws[off.value:off.value + 16 * n_tasks].view(torch.int32).view(n_tasks, 4).cpu().numpy().astype(np.int64)
     row0, nrows = tasks[:, 2], tasks[:, 3]
+    # rows of a task that ANY of its queries owns: the hull [min lo, max hi) of the slots' row ranges, and their exact union
+    qr = ws[off_q.value:off_q.value + 128 * n_tasks].view(torch.int32).view(n_tasks, 16, 2).cpu().numpy().astype(np.int64)
+    rng = qr[:, :, 1]
+    lo_s, hi_s = rng & 0xFFFF, rng >> 16
+    live = np.arange(16)[None, :] < tasks[:, 1:2]
+    hull_rows = int((np.where(live, hi_s, 0).max(1) - np.where(live, lo_s, 1 << 20).min(1)).sum())
+    union_rows = 0
+    for t in np.nonzero(nrows <= 256)[0]:
+        m = np.zeros(257, np.int32)
+        np.add.at(m, lo_s[t][live[t]], 1)
+        np.add.at(m, hi_s[t][live[t]], -1)
+        union_rows += int((np.cumsum(m)[:256] > 0).sum())
     rb = ix.row_stride * 4
     # rows of the probed buckets, each once
     uk = ix.uniq_keys.cpu().numpy().astype(np.int64)
@@ -86,10 +98,10 @@ def main():
     lines_per_xcd = int((((hi + 127) // 128 - lo // 128))[pair // 8].sum()) * 128
     out = {"workload": args.workload, "window_rows": ix.last_window, "tasks": n_tasks, "row_ranges": int(len(uniq_rng)), "row_bytes": rb,
            "probed_bytes": probed_rows * rb, "window_bytes": window_rows * rb, "staged_bytes": staged_rows * rb,
-           "per_xcd_bytes": per_xcd_rows * rb, "lines_once_bytes": lines_once, "lines_per_xcd_bytes": lines_per_xcd,
+           "per_xcd_bytes": per_xcd_rows * rb, "hull_of_slot_ranges_bytes": hull_rows * rb, "union_of_slot_ranges_bytes": union_rows * rb, "lines_once_bytes": lines_once, "lines_per_xcd_bytes": lines_per_xcd,
            "unprobed_rows_in_windows": (window_rows - probed_rows) * rb, "second_and_later_query_groups": (staged_rows - window_rows) * rb,
            "ranges_on_more_than_one_xcd": (per_xcd_rows - window_rows) * rb, "line_granularity": lines_once - window_rows * rb}
-    out["ratios_to_probed"] = {k: round(out[k] / out["probed_bytes"], 3) for k in ("window_bytes", "staged_bytes", "per_xcd_bytes", "lines_once_bytes", "lines_per_xcd_bytes")}
+    out["ratios_to_probed"] = {k: round(out[k] / out["probed_bytes"], 3) for k in ("window_bytes", "staged_bytes", "hull_of_slot_ranges_bytes", "union_of_slot_ranges_bytes", "per_xcd_bytes", "lines_once_bytes", "lines_per_xcd_bytes")}
     print(json.dumps(out))
 
 
