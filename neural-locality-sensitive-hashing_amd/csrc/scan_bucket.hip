@@ -122,9 +122,6 @@ struct BArgs {
     int2 *task_qr;     // tiled schedule: [max_tasks][16] {query id, row range lo | hi << 16} of every (task, slot): the task's group's slice of
                        // inv_q, repeated per row segment, and the rows of the query's bucket inside the task's rows (a whole segment of a
                        // big bucket; the bucket's slice of a shared window).  ONE 8-byte record: one store in bscatter, one load in the scan
-    int2 *task_hull;   // tiled schedule: [max_tasks] rows of the task that ANY of its queries owns, {first, one past the last} relative to the task's
-                       // first row: the whole task for a segment of a big bucket; for a window shared by several small buckets the hull of the
-                       // PROBED buckets' slices (bscatter: atomicMin / atomicMax) -- the scan stages and scores only those rows (r05)
     int32_t *pcell;    // [Q*P] cell of every (query, probe) pair's bucket (bplan looked it up for the counter: bscatter need not again)
     uint64_t *partial;
     long long max_tasks;
@@ -343,8 +340,6 @@ __global__ __launch_bounds__(256) void bscan_kernel(BArgs a, int plan_blocks) {
                 // at about the same time (and, with the chunked XCD map of bscan3, on one XCD's L2)
                 const int si = t / ng, gi = t - si * ng;
                 a.task[tt] = make_int4(po + gi * a.QB, min(a.QB, m - gi * a.QB), row0 + si * a.seg, min(a.seg, s - si * a.seg));
-                // one-segment cells under the small-bucket packing may hold unprobed buckets: their hull is gathered by bscatter
-                if (a.task_hull) a.task_hull[tt] = (ns == 1 && a.cell_of) ? make_int2(0x7FFFFFFF, 0) : make_int2(0, min(a.seg, s - si * a.seg));
             }
         }
     }
@@ -357,7 +352,6 @@ __global__ __launch_bounds__(256) void bscan_kernel(BArgs a, int plan_blocks) {
             if (tt >= a.max_tasks) break;
             const int si = t / hng, gi = t - si * hng;
             a.task[tt] = make_int4(po + gi * a.QB, min(a.QB, hm - gi * a.QB), row0 + si * a.seg, min(a.seg, hs - si * a.seg));
-            if (a.task_hull) a.task_hull[tt] = (hs <= a.seg && a.cell_of) ? make_int2(0x7FFFFFFF, 0) : make_int2(0, min(a.seg, hs - si * a.seg));
         }
     }
 }
@@ -396,10 +390,6 @@ __global__ __launch_bounds__(256) void bscatter_kernel(BArgs a) {
             if (tt >= a.max_tasks) break;
             const int lo = max(lo0 - si * a.seg, 0), hi = min(lo0 + size - si * a.seg, a.seg);   // the bucket's rows inside segment si
             a.task_qr[tt * a.QB + (rel - gi * a.QB)] = make_int2((int32_t)(idx / a.P), lo | (hi << 16));
-            if (a.cell_of && a.coffsets[c + 1] - a.coffsets[c] <= a.seg) {   // a one-segment cell (bscan_kernel left its hull open): widen it by this bucket's slice
-                atomicMin(&a.task_hull[tt].x, lo);
-                atomicMax(&a.task_hull[tt].y, hi);
-            }
         }
     }
 }
@@ -1040,7 +1030,7 @@ __device__ __forceinline__ void merge_query(const BArgs &a, long long q, int lan
 // One task of the tiled schedule, start to finish (operands of the task already requested by the caller: descriptor and
 // the wave's query ids).  `tile` = the workgroup's LDS stage.
 template <int METRIC, int QW, int NW, int TPS>
-__device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, long long t, const int4 desc, const int2 hull, const int (&qid_v)[QW], const int (&rng_v)[QW], int tid, int lane,
+__device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, long long t, const int4 desc, const int2 qr_all, int tid, int lane,
                                                 int wave, [[maybe_unused]] unsigned long long ts_entry) {
     constexpr int NT = 64 * NW;              // threads per workgroup
     constexpr int KB = NLSH_TILED_KB;        // 16-byte chunks per k-block
@@ -1055,22 +1045,27 @@ __device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, lo
     const int nq = __builtin_amdgcn_readfirstlane(desc.y);       // desc.x (first pair of the group) is the wave-level schedule's: the tiled tasks carry their query ids
     // The task's rows, narrowed to the hull of the rows its queries own: a 64-row window shared by several small buckets is staged and
     // scored from the first row of its first PROBED bucket to the last row of its last one (GloVe-1.2M: 1.27x -> 1.10x the rows of the
-    // probed buckets, profiles/r05_traffic_tally.txt; the balanced workloads' scan is bound by the bytes it moves).  Same rows per query,
-    // same chains: same bits.
-    const int h_lo = __builtin_amdgcn_readfirstlane(hull.x);
+    // probed buckets, profiles/r05_traffic_tally.txt; the balanced workloads' scan is bound by the bytes it moves).  The hull is the
+    // min / max over the task's <= 16 slot ranges (two wave-wide DPP reductions per task; a segment of a big bucket gives itself).
+    // Same rows per query, same chains: same bits.
+    const bool slot_live = (lane & (QW * NW - 1)) < nq;
+    const int h_lo = (int)wave_minmax_u32<false>(slot_live ? (uint32_t)(qr_all.y & 0xFFFF) : 0xFFFFu);
+    const int h_hi = (int)wave_minmax_u32<true>(slot_live ? (uint32_t)(qr_all.y >> 16) : 0u);
     const int row0 = __builtin_amdgcn_readfirstlane(desc.z) + h_lo;
-    const int nrows = min(__builtin_amdgcn_readfirstlane(hull.y), __builtin_amdgcn_readfirstlane(desc.w)) - h_lo;  // <= ROWS (the host fixes seg = ROWS)
-    if (nrows <= 0) return;   // wave-uniform, in front of every barrier: a task nobody wrote a slot of (cannot happen while the contract holds)
+    const int nrows = min(h_hi, __builtin_amdgcn_readfirstlane(desc.w)) - h_lo;  // <= ROWS (the host fixes seg = ROWS)
+    if (nrows <= 0) return;   // wave-uniform, in front of every barrier: slot records a stale counter invented (workspace contract; bmerge flags it)
     // queries are dealt round-robin over the waves (slot = wave + NW*jq): a group of 5 queries costs the
     // workgroup 2 query-times per stage (2,1,1,1) instead of 4 (4,1,0,0); the stage barrier waits for the slowest wave
     int nqw = NLSH_DEAL_BLOCKS ? nq - wave * QW : (nq - wave + NW - 1) / NW;
     nqw = __builtin_amdgcn_readfirstlane(nqw < 0 ? 0 : (nqw > QW ? QW : nqw));
 
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const_f32p qs[QW];
     int qid[QW];
 #pragma unroll
     for (int jq = 0; jq < QW; ++jq) {
-        qid[jq] = __builtin_amdgcn_readfirstlane(qid_v[jq]);
+        // ids clamped into [0, Q) so that a slot a stale counter invented (bmerge flags it) addresses nothing outside the queries
+        qid[jq] = min(max(__builtin_amdgcn_readlane(qr_all.x, NLSH_SLOT(wave_u, jq)), 0), (int)a.Q - 1);
         qs[jq] = (const_f32p)(a.qpad + (long long)qid[jq] * a.qpad_stride);
     }
 
@@ -1205,7 +1200,7 @@ __device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, lo
             // rows of the task that belong to THIS query's bucket: all of them for a segment of a big bucket, the bucket's slice of a
             // window shared by several small buckets (the other rows were scored for nothing: the arithmetic of a shared window is what
             // a task of its own would have cost each of those buckets in fixed latency)
-            const int rng = __builtin_amdgcn_readfirstlane(rng_v[jq]);
+            const int rng = __builtin_amdgcn_readlane(qr_all.y, NLSH_SLOT(wave_u, jq));
             const unsigned r_lo = (unsigned)((rng & 0xFFFF) - h_lo), r_n = (unsigned)(rng >> 16) - (unsigned)(rng & 0xFFFF);   // relative to the first row staged
             uint64_t key[TPS];
             // LEAN: every accumulator of the list at or above 2^-96 (wave-uniform test; NaN compares false and takes the general path)
@@ -1300,19 +1295,15 @@ __global__ __launch_bounds__(64 * NW, NLSH_TILED_MIN_WAVES) void bscan3_kernel(B
     // less in front of every task
     const long long tc = t < a.max_tasks ? t : a.max_tasks - 1;
     const int4 desc = a.task[tc];
-    const int2 hull = a.task_hull[tc];                // rows of the task its queries own at all (r05): requested with the descriptor
-    int qid_v[QW], rng_v[QW];                         // the task's query ids and each query's row range inside the task's rows: address known from the task id alone
-#pragma unroll
-    for (int jq = 0; jq < QW; ++jq) {   // slots >= nq hold garbage, never used; ids clamped into [0, Q) so that a slot a stale counter invented (bmerge flags it) addresses nothing outside the queries
-        const int2 qr = a.task_qr[tc * (QW * NW) + NLSH_SLOT(wave, jq)];
-        qid_v[jq] = min(max(qr.x, 0), (int)a.Q - 1);
-        rng_v[jq] = qr.y;
-    }
+    // all 16 {query id, row range} records of the task in ONE load, one record per lane (& 15) -- address known from the task id alone,
+    // requested with the descriptor.  A wave picks its own slots out of it with v_readlane (r04: four 8-byte loads per wave), and the
+    // hull of the rows the task's queries own at all is taken over all sixteen (r05).  Slots >= nq hold garbage, never used.
+    const int2 qr_all = a.task_qr[tc * (QW * NW) + (lane & (QW * NW - 1))];
     if (t >= ntasks) return;
     if (NLSH_ABLATE == 9) return;   // diagnostic: every workgroup leaves after its descriptor loads (what dispatching the grid costs)
     if (NLSH_ABLATE == 8 && desc.y <= NLSH_ABLATE_NQ) return;   // diagnostic: tasks with few queries vanish (what the low-density tasks cost)
     if (NLSH_ABLATE == 7 && desc.w <= 64) return;   // diagnostic: tasks of <= 64 rows vanish (what a kernel without the tail of tiny tasks would take)
-    tiled_task_body<METRIC, QW, NW, TPS>(a, tile, t, desc, hull, qid_v, rng_v, tid, lane, wave, ts_entry);
+    tiled_task_body<METRIC, QW, NW, TPS>(a, tile, t, desc, qr_all, tid, lane, wave, ts_entry);
 }
 
 __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
@@ -1344,7 +1335,7 @@ constexpr int TILED_TPS = NLSH_TILED_TPS;  // 64-row tiles per task of the tiled
 static_assert(64 * TILED_TPS >= 256, "the tiled schedule's segment must hold the widest row window nlsh_build_cells accepts (256 rows)");
 
 struct BWs {
-    size_t pbkt, prec, inv_q, bcount, pairoff, taskoff, bgroups, counters, btot, hits, task, task_qr, task_hull, pcell, partial, qpad, tauq, total;
+    size_t pbkt, prec, inv_q, bcount, pairoff, taskoff, bgroups, counters, btot, hits, task, task_qr, pcell, partial, qpad, tauq, total;
 };
 static void blayout(long long Q, int P, int k, long long max_tasks, long long nb, int d, bool tiled, BWs *w) {
     size_t o = 0;
@@ -1361,7 +1352,6 @@ static void blayout(long long Q, int P, int k, long long max_tasks, long long nb
     w->hits = o;     o += ws_align((size_t)((Q * P + 255) / 256 + 1) * 4);
     w->task = o;     o += ws_align((size_t)max_tasks * sizeof(int4));
     w->task_qr = o;  o += tiled ? ws_align((size_t)max_tasks * TILED_QB * 8) : 0;
-    w->task_hull = o; o += tiled ? ws_align((size_t)max_tasks * 8) : 0;
     w->pcell = o;    o += ws_align(qp);
     w->partial = o;  o += ws_align((size_t)max_tasks * (tiled ? TILED_QB : 8) * k * 8);
     w->qpad = o;     o += tiled ? ws_align((size_t)Q * ((d + 3) / 4) * 16) : 0;
@@ -1424,7 +1414,7 @@ int bucket_scan_run(const BucketScanCall &c) {
     char *base = (char *)c.workspace;
     a.pbkt = (int32_t *)(base + w.pbkt); a.prec = (int4 *)(base + w.prec); a.inv_q = (int32_t *)(base + w.inv_q);
     a.bcount = (int32_t *)(base + w.bcount); a.pairoff = (int32_t *)(base + w.pairoff); a.taskoff = (int32_t *)(base + w.taskoff); a.bgroups = (int32_t *)(base + w.bgroups);
-    a.counters = (int32_t *)(base + w.counters); a.btot = (int32_t *)(base + w.btot); a.hits = (int32_t *)(base + w.hits); a.border = c.bucket_order; a.task = (int4 *)(base + w.task); a.task_qr = c.tiled ? (int2 *)(base + w.task_qr) : nullptr; a.task_hull = c.tiled ? (int2 *)(base + w.task_hull) : nullptr; a.pcell = (int32_t *)(base + w.pcell); a.partial = (uint64_t *)(base + w.partial);
+    a.counters = (int32_t *)(base + w.counters); a.btot = (int32_t *)(base + w.btot); a.hits = (int32_t *)(base + w.hits); a.border = c.bucket_order; a.task = (int4 *)(base + w.task); a.task_qr = c.tiled ? (int2 *)(base + w.task_qr) : nullptr; a.pcell = (int32_t *)(base + w.pcell); a.partial = (uint64_t *)(base + w.partial);
     a.max_tasks = c.max_tasks;
     a.tauq = (unsigned long long *)(base + w.tauq);
 
