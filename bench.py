@@ -599,11 +599,11 @@ def main():
                                "the figure that scales is named by scaling_value_key"),
             "protocol_qps_opt_in": Q * steps / elapsed_opt_in,
             # the field of THIS line a scaling study should read: device-resident steps (results left in HBM, incl. the all-gather + merge at N>1);
-            # predicted ceiling from the one-GPU emulation of the per-rank pipelined local step (profiles/r04_shard_step_profile_pipelined.jsonl:
-            # 0.291 / 0.170 / 0.123 / 0.097 ms at 1 / 2 / 4 / 8 bucket shards): encode + PLAN + merge are replicated on every rank and, at
-            # 8 shards, the step equals the host's time to enqueue it
+            # predicted ceiling from the one-GPU emulation of the per-rank pipelined local step (profiles/r05_shard_step_profile_step_api.jsonl:
+            # 0.295 / 0.170 / 0.116 / 0.090 ms at 1 / 2 / 4 / 8 bucket shards, host enqueue 0.055-0.066 ms per batch through the one-call
+            # step API): encode + PLAN + merge are replicated on every rank
             "scaling_value_key": "device_resident_qps",
-            "scaling_ceiling_note": "per-rank pipelined local step emulated on one GPU: x1.7 / x2.4 / x3.0 at N = 2 / 4 / 8 before the all-gather (replicated per-batch kernels; host enqueue time at N = 8)",
+            "scaling_ceiling_note": "per-rank pipelined local step emulated on one GPU: x1.7 / x2.5 / x3.3 at N = 2 / 4 / 8 before the all-gather (replicated per-batch kernels; 17 HIP runtime calls per batch)",
             "own_slice_qps": None if elapsed_own is None else Q * steps / elapsed_own,
             # N>1 only: the exchange as the data backend itself saw it (ranks counted by an all-reduce of ones, devices by an all-gather of PCI ids)
             "collective": collective,
