@@ -395,6 +395,12 @@ def test_deferred_release_never_holds_more_than_two_results():
     assert ix._held == []
 
 
+def test_design_md_stays_within_120_columns():
+    """DESIGN.md is wrapped (tools/wrap_md.py re-flows it; tables and code are reported, not altered)."""
+    over = [(i + 1, len(ln)) for i, ln in enumerate(open(os.path.join(ROOT, "DESIGN.md")).read().split("\n")) if len(ln) > 120]
+    assert not over, over[:5]
+
+
 def test_graft_entry_build_passes_on_cpu():
     """`__graft_entry__.build()` is the driver's "does it build" check: hipcc cross-compiles gfx950 without a GPU, the library's ABI version
     must be the header's (r04 bumped it to 2 and the entry point still asserted 1 until this test existed), every declared symbol resolves."""
