@@ -167,7 +167,8 @@ size_t nlsh_scan_workspace(int64_t Q, int P, int k, int64_t max_tasks, int64_t n
  * Outputs [dev]: out_dist [Q, k] ascending, +inf padded; out_idx [Q, k] global row ids, -1 padded;
  * out_keys (nullable) [Q, k] the 64-bit sort keys (monotone(dist) << 32 | id; ~0 padded) used by
  * nlsh_merge_topk; out_ncand [Q] candidates per query; status [2] = {tasks needed, flag}: flag 0 = complete,
- * 1 = task table overflow (repeat with max_tasks >= status[0]), 2 = workspace contract violated (below).
+ * 1 = task table overflow (repeat with max_tasks >= status[0]), 2 = workspace contract violated (below), 3 = the cells handed
+ * to nlsh_scan_topk_cells_phase hold a shared window of more than 256 rows (not from nlsh_build_cells: results incomplete).
  * Order is (distance asc, row id asc): deterministic refinement of torch.topk's tie order.
  * A query's candidate list is cut into segments of `seg_rows` rows (0 = default), one wavefront
  * each; max_tasks bounds the number of segments the workspace holds: if status[1] != 0 the

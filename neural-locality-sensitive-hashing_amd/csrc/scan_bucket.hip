@@ -378,6 +378,14 @@ __global__ __launch_bounds__(256) void bscatter_kernel(BArgs a) {
     // `size` = rows of the BUCKET: the query's candidate count, and (size + seg - 1) / seg = its partial lists -- one per row segment of
     // a big bucket, exactly one for a bucket inside a shared window (window_rows <= seg)
     const int row0 = a.offsets[b], size = a.offsets[b + 1] - row0;
+    // A bucket that is only PART of its cell lives in a shared window, and a shared window must fit one segment (nlsh_build_cells:
+    // window_rows <= 256 = the segment, static_assert below): this kernel takes the bucket's partial-list count from its own size and
+    // clamps its row range to the segment.  Cells from elsewhere that break the rule are refused (status[1] = 3), never scanned short.
+    if (a.cell_of && size < a.coffsets[c + 1] - a.coffsets[c] && a.coffsets[c + 1] - a.coffsets[c] > a.seg) {
+        a.status[1] = 3;
+        a.prec[idx] = make_int4(0, 0, 0, 0);
+        return;
+    }
     const int t0 = a.taskoff[c] + gi, ng = a.bgroups[c];
     a.prec[idx] = make_int4(t0, rel - gi * a.QB, size, ng);
     if (a.task_qr) {

@@ -410,6 +410,10 @@ class Indexer:
         """status[1] == 1: the task table was too small; grow it, the caller repeats the call.
         status[1] == 2: the PLAN phase found the per-bucket counters at the head of the workspace non-zero on entry
         (include/nlsh_hip.h, workspace contract): the batch got no tasks; drop the workspaces and fail loudly."""
+        if flag == 3:
+            self._ws.clear()
+            raise _capi.NlshHipError(_capi.E_INVALID, "scan_topk(tiled): the cells hold a shared window wider than one 256-row segment "
+                                                      "(cells must come from nlsh_build_cells with window_rows <= 256)")
         if flag == 2:
             self._ws.clear()
             raise _capi.NlshHipError(_capi.E_WORKSPACE, "scan_topk(bucket-major): the pair counters at the head of the workspace "

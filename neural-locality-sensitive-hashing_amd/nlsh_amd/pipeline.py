@@ -215,6 +215,8 @@ class QueryPipeline:
         """True if any slot's last batch did not fit the task table (results incomplete: rebuild the pipeline).
         Raises if a slot's PLAN phase found its workspace head non-zero on entry (status 2: the batch got no tasks)."""
         flags = [int(s.status.cpu()[1]) for s in self.slots]
+        if 3 in flags:
+            raise _capi.NlshHipError(_capi.E_INVALID, "pipeline slot: the cells hold a shared window wider than one 256-row segment")
         if 2 in flags:
             raise _capi.NlshHipError(_capi.E_WORKSPACE, "pipeline slot: the pair counters at the head of the workspace were not "
                                                         "zero on entry (workspace contract, include/nlsh_hip.h)")

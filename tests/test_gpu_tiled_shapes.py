@@ -271,6 +271,39 @@ def test_build_cells_is_the_greedy_packing(window):
     assert multi.any() and rows[multi].max() <= window               # shared windows exist and none exceeds the window
 
 
+def test_foreign_cells_with_a_window_wider_than_a_segment_are_refused():
+    """the tiled scan assumes that a window shared by several buckets fits ONE 256-row segment (what nlsh_build_cells
+    guarantees).  Cells from elsewhere that pack small buckets into a wider window are refused on the device (status flag 3 ->
+    NlshHipError E_INVALID), never scanned with rows missing; the workspace stays usable afterwards."""
+    from nlsh_amd.data import SIFT
+    from nlsh_amd.indexer import Indexer
+    rng = np.random.default_rng(5)
+    d, k = 32, 5
+    sizes = np.full(40, 20)                                         # 40 buckets of 20 rows: 800 rows
+    keys = np.repeat(np.arange(40, dtype=np.int32) * 3, sizes)
+    corpus = rng.standard_normal((len(keys), d)).astype(np.float32)
+    queries = rng.standard_normal((8, d)).astype(np.float32)
+    Ws, bs = synth.make_weights([d, 8, 16], seed=1)
+    ix = Indexer(make_hashing(d, (8,), 16, Ws, bs, compat=False), dev(corpus), SIFT.distance, compat=False, algo="tiled", corpus_keys=dev(keys),
+                 window_rows=64)
+    key_lists = [[int(3 * ((q * 5 + j) % 40)) for j in range(4)] for q in range(8)]
+    good = ix.query_with_keys(dev(queries), key_lists, k=k)
+    # foreign cells: buckets 0..19 (400 rows) in ONE cell, the rest one cell each
+    cell_of = np.concatenate([np.zeros(20, np.int32), np.arange(1, 21, dtype=np.int32)])
+    offs = ix.offsets.cpu().numpy()
+    cell_offsets = np.concatenate([[0], offs[20:]]).astype(np.int32)
+    nc = 21
+    order = np.argsort(-np.diff(cell_offsets), kind="stable").astype(np.int32)
+    ix._cells[64] = (dev(cell_of), dev(cell_offsets), dev(order), nc)
+    ix._max_tasks.clear()
+    with pytest.raises(_capi.NlshHipError) as err:
+        ix.query_with_keys(dev(queries), key_lists, k=k)
+    assert err.value.code == _capi.E_INVALID and "256-row segment" in str(err.value)
+    del ix._cells[64]                                               # back to the library's own cells: same answer as before
+    again = ix.query_with_keys(dev(queries), key_lists, k=k)
+    assert again[0] == good[0] and again[1] == good[1]
+
+
 @pytest.mark.parametrize("metric", ["l2", "cosine"])
 @pytest.mark.parametrize("d", [128, 100])
 def test_shared_windows_change_no_result_bit(metric, d):
