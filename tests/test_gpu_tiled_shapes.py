@@ -271,6 +271,26 @@ def test_build_cells_is_the_greedy_packing(window):
     assert multi.any() and rows[multi].max() <= window               # shared windows exist and none exceeds the window
 
 
+@pytest.mark.parametrize("metric,d", [("cosine", 100), ("l2", 72)])
+def test_padded_rows_change_no_result_bit(metric, d):
+    """`Indexer(row_align=32)` starts every row of the bucket-sorted copy on a 128-byte line (100-d: 400 -> 512 bytes per row; an
+    r05 traffic experiment).  The kernels walk d, not the stride: every schedule must return the bits of the
+    packed layout."""
+    from nlsh_amd.data import Glove, SIFT
+    from nlsh_amd.indexer import Indexer
+    corpus, queries, corpus_keys, key_lists, _ = _build(d, metric, seed=4000 + d)
+    Ws, bs = synth.make_weights([d, 32, 16], seed=d)
+    hashing = make_hashing(d, (32,), 16, Ws, bs, compat=False)
+    dist_fn = SIFT.distance if metric == "l2" else Glove.distance
+    for algo in ("tiled", "query"):
+        base = Indexer(hashing, dev(corpus), dist_fn, compat=False, algo=algo, corpus_keys=dev(corpus_keys))
+        wide = Indexer(hashing, dev(corpus), dist_fn, compat=False, algo=algo, corpus_keys=dev(corpus_keys), row_align=32)
+        assert wide.row_stride == (d + 31) // 32 * 32 > base.row_stride == (d + 3) // 4 * 4
+        r0, r1 = base.query_with_keys(dev(queries), key_lists, k=10), wide.query_with_keys(dev(queries), key_lists, k=10)
+        assert r0[0] == r1[0] and r0[1] == r1[1]
+        assert torch.equal(r0[3], r1[3]) and torch.equal(r0[2].view(torch.int32), r1[2].view(torch.int32))
+
+
 def test_foreign_cells_with_a_window_wider_than_a_segment_are_refused():
     """the tiled scan assumes that a window shared by several buckets fits ONE 256-row segment (what nlsh_build_cells
     guarantees).  Cells from elsewhere that pack small buckets into a wider window are refused on the device (status flag 3 ->
