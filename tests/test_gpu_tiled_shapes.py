@@ -271,6 +271,37 @@ def test_build_cells_is_the_greedy_packing(window):
     assert multi.any() and rows[multi].max() <= window               # shared windows exist and none exceeds the window
 
 
+@pytest.mark.parametrize("scale", [1e-25, 3e-16, 1e-12, 1.0, 3e18])
+def test_tiled_l2_at_extreme_magnitudes_is_still_the_oracle_bit_for_bit(scale):
+    """The r05 epilogue takes square roots without hipcc's range scaling when every accumulator of a list is >= 2^-96 and falls back to
+    sqrtf otherwise (one wave-uniform guard per list).  Both sides of the guard, the zero distance of a query that IS a corpus row
+    (sqrt(d) * 1e-6 through the eps term), sums that underflow to denormals and sums that overflow to +inf must all give the oracle's
+    bits and its (distance, id) order."""
+    from nlsh_amd.data import SIFT
+    from nlsh_amd.indexer import Indexer
+    rng = np.random.default_rng(11)
+    d, k, N, Qn = 64, 10, 3000, 48
+    corpus = (rng.standard_normal((N, d)) * scale).astype(np.float32)
+    queries = (rng.standard_normal((Qn, d)) * scale).astype(np.float32)
+    twins = rng.choice(N, 16, replace=False)
+    queries[:16] = corpus[twins]                                       # exact matches: every term is (0 + eps)^2
+    keys = rng.integers(0, 12, N).astype(np.int32) * 7 - 20           # 12 buckets of ~250 rows: several tiles per task
+    Ws, bs = synth.make_weights([d, 8, 16], seed=2)
+    ix = Indexer(make_hashing(d, (8,), 16, Ws, bs, compat=False), dev(corpus), SIFT.distance, compat=False, algo="tiled", corpus_keys=dev(keys))
+    key_lists = [[int(v) * 7 - 20 for v in rng.choice(12, 3, replace=False)] for _ in range(Qn)]
+    for i, row in enumerate(twins):                                    # a twin's bucket is among the buckets its query probes
+        key_lists[i] = list(dict.fromkeys([int(keys[row])] + key_lists[i]))
+    res, nc, dist, idx = ix.query_with_keys(dev(queries), key_lists, k=k)
+    perm, uniq, offs = oracle.build_csr(keys.astype(np.int64))
+    qk, nk = oracle.keys_from_lists(key_lists)
+    od, oi, onc = oracle.query_batch(corpus, perm, uniq, offs, queries, qk, nk, k, "l2")
+    assert nc == onc.tolist()
+    assert np.array_equal(dist.cpu().numpy().view(np.uint32), od.view(np.uint32))
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    if scale == 1.0:
+        assert np.all(od[:16, 0] < 1e-4) and np.array_equal(oi[:16, 0], twins)   # the twins came first, at sqrt(d) * 1e-6
+
+
 @pytest.mark.parametrize("metric,d", [("cosine", 100), ("l2", 72)])
 def test_padded_rows_change_no_result_bit(metric, d):
     """`Indexer(row_align=32)` starts every row of the bucket-sorted copy on a 128-byte line (100-d: 400 -> 512 bytes per row; an
