@@ -93,7 +93,9 @@ extern "C" int nlsh_query_step_enqueue(nlsh_step_t *s, const float *queries, int
     NLSH_REQUIRE(!s->done_pending, NLSH_E_INVALID, "query_step_enqueue: the slot's previous batch was not released (nlsh_step_release)");
     const hipStream_t front = (hipStream_t)s->d.front, mid = (hipStream_t)s->d.mid, tail = (hipStream_t)s->d.tail;
     NLSH_CHECK_HIP(hipStreamWaitEvent(front, s->done, 0));            // the slot's previous batch has left the tail: its buffers are free
-    if (producer && (hipStream_t)producer != front) {                 // the batch may still be in flight on the stream that produced it
+    // the batch may still be in flight on the stream that produced it.  NULL is a stream like any other here -- the default stream, where
+    // torch produces a tensor unless told otherwise -- and the stage streams are non-blocking ones that do NOT order themselves behind it
+    if ((hipStream_t)producer != front) {
         NLSH_CHECK_HIP(hipEventRecord(s->ready, (hipStream_t)producer));
         NLSH_CHECK_HIP(hipStreamWaitEvent(front, s->ready, 0));
     }

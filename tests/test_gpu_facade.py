@@ -240,6 +240,36 @@ def test_pipeline_survives_dropped_batches_and_weight_updates():
     assert not torch.equal(out[1], want[1][1])                        # flipped bits: other buckets, other answers
 
 
+def test_pipeline_waits_for_a_batch_still_being_produced_on_the_default_stream():
+    """torch produces a tensor on the DEFAULT stream (handle NULL) unless told otherwise, and the pipeline's stage streams are
+    non-blocking ones that do not order themselves behind it: `nlsh_query_step_enqueue` must make the front stream wait for the
+    producer stream whatever its handle (include/nlsh_hip.h).  The batch buffer is written LAST on the default stream, behind a few
+    milliseconds of unrelated work; submitted at once, the answers must be those of the finished batch."""
+    from nlsh_amd.data import SIFT
+    from nlsh_amd.indexer import Indexer
+    from nlsh_amd.pipeline import QueryPipeline
+    N, Q, d, H, k, P = 60000, 2000, 128, 10, 10, 6
+    corpus, mean, std = synth.standardise(synth.sift_like(N, d, seed=61))
+    batch = dev(synth.standardise(synth.sift_like(Q, d, seed=62), mean, std)[0])
+    Ws, bs = synth.make_weights([d, 64, H], seed=61)
+    ix = Indexer(make_hashing(d, (64,), H, Ws, bs), dev(corpus), SIFT.distance)
+    want = tuple(t.clone() for t in ix.query_tensors(batch, k=k, hash_times=P, seed=3)[:3])
+    pipe = QueryPipeline(ix, batch, k=k, hash_times=P, depth=3)
+    assert torch.cuda.current_stream().cuda_stream == 0              # the case under test: the producer is the NULL handle
+    big = torch.randn(4096, 4096, device="cuda")
+    for trial in range(3):
+        staged = torch.zeros_like(batch)                             # zeros hash to one bucket: a front stage that ran early shows
+        torch.cuda.synchronize()
+        acc = big
+        for _ in range(12):
+            acc = acc @ big                                          # milliseconds of work queued in front of the copy
+        staged.copy_(batch)
+        out = pipe.submit(staged, seed=3)
+        pipe.synchronize()
+        assert torch.equal(out[1], want[1]) and torch.equal(out[0], want[0]) and torch.equal(out[2], want[2]), trial
+        del acc
+
+
 # ----------------------------------------------------------------------------- query() in row ranges (host/device overlap)
 @pytest.mark.parametrize("compat", [True, False])
 def test_query_in_row_ranges_equals_the_single_range_call(compat):
