@@ -286,8 +286,8 @@ int nlsh_step_destroy(nlsh_step_t *step);
 /* New packed weights (nlsh_encoder_pack) for the batches enqueued from now on (a training step between two batches). */
 int nlsh_step_set_weights(nlsh_step_t *step, const float *packed);
 /* queries [dev] fp32 [Q, d] with row stride q_stride.  producer: the stream the batch was produced on (NULL = the default stream, as
- * for every nlsh_stream_t of this header) -- the front stream waits for what is queued there now; pass the step's own front stream
- * when there is nothing to wait for.  ev_scan_begin / ev_scan_end (nullable hipEvent_t): recorded around the scan kernel. */
+ * for every nlsh_stream_t of this header) -- the front stream waits for what is queued there now (one stream query; an event only
+ * when the producer has work in flight); pass the step's own front stream when there is never anything to wait for.  ev_scan_begin / ev_scan_end (nullable hipEvent_t): recorded around the scan kernel. */
 int nlsh_query_step_enqueue(nlsh_step_t *step, const float *queries, int64_t q_stride, uint64_t seed, nlsh_stream_t producer,
                             void *ev_scan_begin, void *ev_scan_end);
 int nlsh_step_release(nlsh_step_t *step);   /* hold_done steps only: the batch ends HERE on the tail stream */

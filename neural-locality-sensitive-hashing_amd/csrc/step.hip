@@ -93,9 +93,17 @@ extern "C" int nlsh_query_step_enqueue(nlsh_step_t *s, const float *queries, int
     NLSH_REQUIRE(!s->done_pending, NLSH_E_INVALID, "query_step_enqueue: the slot's previous batch was not released (nlsh_step_release)");
     const hipStream_t front = (hipStream_t)s->d.front, mid = (hipStream_t)s->d.mid, tail = (hipStream_t)s->d.tail;
     NLSH_CHECK_HIP(hipStreamWaitEvent(front, s->done, 0));            // the slot's previous batch has left the tail: its buffers are free
-    // the batch may still be in flight on the stream that produced it.  NULL is a stream like any other here -- the default stream, where
-    // torch produces a tensor unless told otherwise -- and the stage streams are non-blocking ones that do NOT order themselves behind it
-    if ((hipStream_t)producer != front) {
+    // The batch may still be in flight on the stream that produced it.  NULL is a stream like any other here -- the default stream, where
+    // torch produces a tensor unless told otherwise -- and the stage streams are non-blocking ones that do NOT order themselves behind it.
+    // A producer stream with nothing in flight (one query, ~1 us: the steady state of a loop over batches made earlier) needs no event.
+    bool wait_producer = (hipStream_t)producer != front;
+    if (wait_producer) {
+        const hipError_t qe = hipStreamQuery((hipStream_t)producer);
+        if (qe == hipSuccess) wait_producer = false;
+        else if (qe == hipErrorNotReady) (void)hipGetLastError();     // an answer, not a failure
+        else NLSH_CHECK_HIP(qe);
+    }
+    if (wait_producer) {
         NLSH_CHECK_HIP(hipEventRecord(s->ready, (hipStream_t)producer));
         NLSH_CHECK_HIP(hipStreamWaitEvent(front, s->ready, 0));
     }

@@ -113,6 +113,9 @@ class QueryPipeline:
         self._bind_weights()
         self.n_submitted = 0
         self.last_slot = None
+        # the slots' buffers were zero-filled (and the weights packed) on the caller's current stream; the stage streams do not order
+        # themselves behind it, and the first `submit` may come from another stream: nothing of the set-up is left in flight
+        torch.cuda.current_stream(dev).synchronize()
 
     def _make_step(self, s):
         """The slot's `nlsh_step_t`: everything about its launches that does not change from batch to batch."""
