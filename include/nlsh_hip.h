@@ -9,7 +9,8 @@
  * Conventions
  *   - plain pointers and sizes only; every pointer marked [dev] is a DEVICE pointer
  *     (hipMalloc / torch tensor.data_ptr()), [host] is host memory;
- *   - the caller allocates every buffer (workspace sizes come from the *_workspace queries);
+ *   - the caller allocates every buffer (workspace sizes come from the *_workspace queries; a workspace starts on a 16-byte
+ *     boundary -- any hipMalloc'ed or torch tensor does -- and is refused otherwise);
  *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*, NULL = default
  *     stream); no call synchronises the device or allocates device memory;
  *   - return 0 on success, a negative NLSH_E_* code on failure; never throws; the message of

@@ -216,6 +216,7 @@ extern "C" int nlsh_build_csr(const int32_t *keys, int64_t n, int32_t *perm, int
     int rc = csr_layout(n, &w, s);
     if (rc != NLSH_OK) return rc;
     NLSH_REQUIRE(workspace_bytes >= w.total, NLSH_E_WORKSPACE, "build_csr: workspace %zu < %zu", workspace_bytes, w.total);
+    NLSH_REQUIRE(((uintptr_t)workspace & 15) == 0, NLSH_E_INVALID, "build_csr: the workspace must be 16-byte aligned");
     char *base = (char *)workspace;
     int32_t *sk = (int32_t *)(base + w.sk), *iota = (int32_t *)(base + w.iota);
     int32_t *flags = (int32_t *)(base + w.flags), *rank = (int32_t *)(base + w.rank);
@@ -251,6 +252,7 @@ extern "C" int nlsh_bucket_order(const int32_t *offsets, int64_t n_buckets, int3
     int rc = order_layout(n_buckets, &w, s);
     if (rc != NLSH_OK) return rc;
     NLSH_REQUIRE(workspace_bytes >= w.total, NLSH_E_WORKSPACE, "bucket_order: workspace %zu < %zu", workspace_bytes, w.total);
+    NLSH_REQUIRE(((uintptr_t)workspace & 15) == 0, NLSH_E_INVALID, "bucket_order: the workspace must be 16-byte aligned");
     char *base = (char *)workspace;
     uint32_t *sizes = (uint32_t *)(base + w.sizes), *sorted_sizes = (uint32_t *)(base + w.sorted_sizes);
     int32_t *idx = (int32_t *)(base + w.idx);
@@ -307,6 +309,7 @@ extern "C" int nlsh_build_cells(const int32_t *offsets, int64_t n_buckets, int w
     int rc = cell_layout(n_buckets, &w, s);
     if (rc != NLSH_OK) return rc;
     NLSH_REQUIRE(workspace_bytes >= w.total, NLSH_E_WORKSPACE, "build_cells: workspace %zu < %zu", workspace_bytes, w.total);
+    NLSH_REQUIRE(((uintptr_t)workspace & 15) == 0, NLSH_E_INVALID, "build_cells: the workspace must be 16-byte aligned");
     char *base = (char *)workspace;
     int32_t *flags = (int32_t *)(base + w.flags), *rank = (int32_t *)(base + w.rank);
     const long long spans = (n_buckets + CELL_SPAN - 1) / CELL_SPAN;

@@ -311,6 +311,9 @@ extern "C" int nlsh_scan_topk_cells_phase(const float *corpus_sorted, int64_t ro
     NLSH_REQUIRE((row_stride & 3) == 0 && row_stride >= d && ((uintptr_t)corpus_sorted & 15) == 0, NLSH_E_INVALID,
                  "scan_topk: row_stride=%lld must be a multiple of 4 and >= d, corpus 16-byte aligned", (long long)row_stride);
     NLSH_REQUIRE(q_stride >= d, NLSH_E_INVALID, "scan_topk: q_stride < d");
+    // the task table and the partial lists are read with 16- and 8-byte accesses at 256-byte offsets of the workspace
+    NLSH_REQUIRE(((uintptr_t)workspace & 15) == 0 && ((uintptr_t)out_keys & 7) == 0, NLSH_E_INVALID,
+                 "scan_topk: the workspace must be 16-byte aligned and out_keys 8-byte aligned");
     if (seg_rows == 0) seg_rows = 512;
     seg_rows = (seg_rows + 63) / 64 * 64;
     hipStream_t s = (hipStream_t)stream;

@@ -57,6 +57,10 @@ def test_step_descriptor_layout_and_host_side_validation():
     assert lib.nlsh_query_step_enqueue(None, None, 0, 0, None, None, None) == _capi.E_INVALID
     assert lib.nlsh_step_busy(None) == _capi.E_INVALID and lib.nlsh_step_release(None) == _capi.E_INVALID
     assert lib.nlsh_step_destroy(None) == _capi.OK
+    # a workspace that does not start on a 16-byte boundary is refused before anything is launched (fake non-null pointers: none is read)
+    fake = 0x10000
+    need = lib.nlsh_bucket_order_workspace(1000)
+    assert lib.nlsh_bucket_order(fake, 1000, fake, fake + 4, need, None) == _capi.E_INVALID and b"16-byte" in lib.nlsh_last_error()
 
 
 def test_weights_signature_follows_the_module_as_it_is_now(monkeypatch):
