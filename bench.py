@@ -603,7 +603,7 @@ def main():
             # 0.295 / 0.170 / 0.116 / 0.090 ms at 1 / 2 / 4 / 8 bucket shards, host enqueue 0.055-0.066 ms per batch through the one-call
             # step API): encode + PLAN + merge are replicated on every rank
             "scaling_value_key": "device_resident_qps",
-            "scaling_ceiling_note": "per-rank pipelined local step emulated on one GPU: x1.7 / x2.5 / x3.3 at N = 2 / 4 / 8 before the all-gather (replicated per-batch kernels; 17 HIP runtime calls per batch)",
+            "scaling_ceiling_note": "per-rank pipelined local step emulated on one GPU: x1.75 / x2.5 / x3.2 at N = 2 / 4 / 8 before the all-gather (replicated per-batch kernels; 18 HIP runtime calls per batch)",
             "own_slice_qps": None if elapsed_own is None else Q * steps / elapsed_own,
             # N>1 only: the exchange as the data backend itself saw it (ranks counted by an all-reduce of ones, devices by an all-gather of PCI ids)
             "collective": collective,
