@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--row-align", type=int, default=4, help="row stride of the sorted corpus copy = ceil(d / A) * A floats (32: every row starts on a 128-byte line)")
     ap.add_argument("--zeros", action="store_true", help="zero the grouped corpus and the queries after the index and the keys exist: same tasks and instruction stream, operands that toggle nothing (DVFS probe; pair with -DNLSH_ABLATE=5, ties change the selection)")
+    ap.add_argument("--riffle", default="", choices=["", "half", "third", "twothirds", "rev", "rand"], help="experiment: re-deal the static size order of the cells (proportional merge of its heavy prefix holding this share of the rows with the rest; rev / rand as sensitivity checks)")
     ap.add_argument("--order", default="", choices=["", "pairs", "work", "density"], help="experiment: schedule order of the buckets recomputed on the host from THIS batch's keys (pairs: by (query, probe) pairs hitting the bucket; work: pairs x rows; density: full 16-query groups first, then by pairs), in place of the static size order")
     ap.add_argument("--tight", type=float, default=0.0, help="task table (= grid of the one-shot scan kernel) set to TIGHT x the tasks the batch needs (experiment; 0: the facade's estimate)")
     args = ap.parse_args()
@@ -73,6 +74,35 @@ def main():
         key = {"pairs": m * 100000 + size, "work": m * size, "density": np.minimum(m, 16) * 10**9 + m * 4096 + size}[args.order]
         order = np.argsort(-key, kind="stable").astype(np.int32)
         ix.bucket_order = torch.from_numpy(order).cuda()
+    if args.riffle:
+        # experiment: the static size order re-dealt so that heavy (many rows: compute-leaning) and light (few rows: memory-leaning) cells
+        # are in flight together over the whole launch instead of one after the other
+        ix.scan_tensors(qg, keys, nkeys, k=10)
+        w = ix.last_window
+        if w:
+            cell_of, cell_offsets, cell_order, nc = ix._cells[w]
+            co = cell_offsets.cpu().numpy().astype(np.int64)
+            sizes_by_id, order = co[1:] - co[:-1], cell_order.cpu().numpy()
+        else:
+            sizes_by_id, order = ix.bucket_sizes.astype(np.int64), ix.bucket_order.cpu().numpy()
+        sz = sizes_by_id[order]
+        n = len(order)
+        if args.riffle == "rev":
+            new = order[::-1].copy()
+        elif args.riffle == "rand":
+            new = order[np.random.default_rng(1).permutation(n)]
+        else:
+            frac = {"half": 0.5, "third": 1.0 / 3, "twothirds": 2.0 / 3}[args.riffle]
+            cut = int(np.searchsorted(np.cumsum(sz), frac * sz.sum()))
+            H, Lt = order[:cut], order[cut:]
+            # proportional merge: position i of the merged list comes from H when its share of H consumed lags
+            pos = np.concatenate([(np.arange(len(H)) + 0.5) / max(len(H), 1), (np.arange(len(Lt)) + 0.5) / max(len(Lt), 1)])
+            new = np.concatenate([H, Lt])[np.argsort(pos, kind="stable")]
+        new_t = torch.from_numpy(np.ascontiguousarray(new).astype(np.int32)).cuda()
+        if w:
+            ix._cells[w] = (cell_of, cell_offsets, new_t, nc)
+        else:
+            ix.bucket_order = new_t
     windows = ([None] if not args.window else [int(w) for w in args.window.split(",")]) * max(1, args.rounds)
     ref_out, first, by_window = None, None, {}
     # rows of the buckets this batch probes at all (each counted once): what a schedule that fetches every needed row exactly once reads
