@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NLSH_ABI_VERSION 3   /* 3 (r05): pipelined batch slots (nlsh_step_*, nlsh_query_step_enqueue); 2 (r04): cells */
+#define NLSH_ABI_VERSION 4   /* 4 (r06): nlsh_query_batch; the workspace counters are handed back by the PLAN phase; 3 (r05): pipelined batch slots (nlsh_step_*, nlsh_query_step_enqueue); 2 (r04): cells */
 
 typedef void *nlsh_stream_t; /* hipStream_t */
 
@@ -177,12 +177,12 @@ size_t nlsh_scan_workspace(int64_t Q, int P, int k, int64_t max_tasks, int64_t n
  * Workspace contract of the bucket-major schedules (algo 1, 2): the per-bucket pair counters live in the first
  * 4 * n_buckets bytes of the workspace (an offset that does not depend on Q, P or max_tasks).  Those bytes must be ZERO
  * before the first call that uses the buffer and must not be written by anything else afterwards (do not lend the buffer
- * to algo 0 calls in between); every completed call leaves them zero again (the scatter step hands every count back),
- * which is what saves a clearing launch per batch.  The contract is CHECKED on the device, twice: the PLAN phase holds the sum
- * of the counters against the (query, probe) pairs it counted itself and rejects negative counters -- on a mismatch the batch
- * gets no task at all and every query's result is empty --, and the MERGE phase verifies that every counter is back at zero
- * (stale counts that cancel in the sum mis-size individual query lists: all accesses stay in bounds, the lists are wrong).
- * Either way status[1] = 2: zero the first 4 * n_buckets bytes and repeat the call (the Python facade raises NLSH_E_WORKSPACE).
+ * to algo 0 calls in between); every PLAN phase leaves them zero again (the step that turns the counts into list offsets reads
+ * and resets each counter), which is what saves a clearing launch per batch.  The contract is CHECKED on the device: the PLAN
+ * phase holds the sum of the counters against the (query, probe) pairs it counted itself, rejects negative counters and rejects
+ * any pair that drew a negative slot from its counter -- stale counts that cancel in the sum include a negative one, so every
+ * way a stale count can enter a batch is covered --; on a violation the batch gets no task at all, every query's result is
+ * empty and status[1] = 2 (the Python facade raises NLSH_E_WORKSPACE).  The counters are zero again after the refused call.
  * ev_scan_begin / ev_scan_end (nullable hipEvent_t): recorded on `stream` immediately before and
  * after the scan kernel, so a caller can time the HBM-bound kernel alone (bench.py roofline).
  * Limits: d <= NLSH_MAX_DIM, k <= NLSH_MAX_K, P <= NLSH_MAX_PROBES. */
@@ -239,8 +239,8 @@ int nlsh_scan_topk_cells_phase(const float *corpus_sorted, int64_t row_stride, i
 /* ---------------------------------------------------------------------------------------------
  * One pipelined query batch per call.  Replaces, for a caller that streams batches, the whole body of Indexer.query
  * (nlsh/indexer.py:56-96: hashing.hash on the batch :59 via Indexer.hash :40-54, then the per-query loop :62-95) by ONE
- * enqueue: nlsh_encode_hash + the PLAN, SCAN and MERGE phases of nlsh_scan_topk_cells_phase (seven launches) and the events
- * that order them across three or four streams.  A step (slot) is built once from everything that does not change between
+ * enqueue: nlsh_encode_hash + the PLAN, SCAN and MERGE phases of nlsh_scan_topk_cells_phase (five launches since r06: the bucket
+ * lookup of the PLAN phase runs in the encode's epilogue) and the events that order them across three or four streams.  A step (slot) is built once from everything that does not change between
  * batches of one shape; nlsh_query_step_enqueue then takes the batch pointer, its row stride and the Philox seed.  The library
  * owns the slot's events; streams and buffers are the caller's.  Results are those of the separate calls, bit for bit.
  *
@@ -277,7 +277,8 @@ typedef struct nlsh_step_desc {
     void *workspace;
     size_t workspace_bytes;
     int64_t max_tasks;
-    /* streams (hipStream_t): front, mid, tail must be three different non-default streams; plan may be NULL */
+    /* streams (hipStream_t): front, mid, tail must be three different non-default streams; plan may be NULL, else a fourth different
+     * one.  Equal handles are refused by nlsh_step_create, as is every argument the scan call itself would refuse. */
     nlsh_stream_t front, plan, mid, tail;
 } nlsh_step_desc_t;
 
@@ -292,6 +293,16 @@ int nlsh_step_set_weights(nlsh_step_t *step, const float *packed);
 int nlsh_query_step_enqueue(nlsh_step_t *step, const float *queries, int64_t q_stride, uint64_t seed, nlsh_stream_t producer,
                             void *ev_scan_begin, void *ev_scan_end);
 int nlsh_step_release(nlsh_step_t *step);   /* hold_done steps only: the batch ends HERE on the tail stream */
+/* The same batch for a caller that does not pipeline: everything on ONE stream, nothing kept between calls (the stream handles and
+ * hold_done of `desc` are ignored; desc_bytes as for nlsh_step_create).  Replaces one whole Indexer.query body (nlsh/indexer.py:56-96)
+ * by five launches: nlsh_encode_hash with the bucket lookup of :68 in its epilogue (the keys never leave the workgroup that made them
+ * before they are looked up), two launches that lay out the (row segment, query group) tasks, the scan kernel, the merge.
+ * row0: index of the batch's first row in the Philox counter of the multi-probe draws (as nlsh_encode_hash's row0: a row range of a
+ * larger batch draws what it would have drawn inside it; desc->n_multi_rows counts from the range's first row).
+ * lookup_done != 0: skip the hashing and repeat the scan part on the keys the previous call of this batch left in desc->qkeys --
+ * the retry after status[1] = 1 (task table too small), with a larger max_tasks / workspace. */
+int nlsh_query_batch(const nlsh_step_desc_t *desc, size_t desc_bytes, const float *queries, int64_t q_stride, uint64_t seed,
+                     int64_t row0, int lookup_done, void *ev_scan_begin, void *ev_scan_end, nlsh_stream_t stream);
 /* 1 while the slot's last batch has not left the tail stream, 0 once it has, < 0 on error.  Never blocks. */
 int nlsh_step_busy(nlsh_step_t *step);
 

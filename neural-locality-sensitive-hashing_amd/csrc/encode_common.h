@@ -40,6 +40,10 @@ enum { ENC_FORM_H16 = 0, ENC_FORM_SINGLE, ENC_FORM_SINGLE_WIDE, ENC_FORM_BUILD12
 int encode_plan_fill(EncPlan &p, int64_t n, int n_layers, const int *dims, const float *packed, int act, int key_mode, int n_probes,
                      int64_t n_multi_rows, int64_t row0, float *z_out, float *probs_out, uint32_t *code_out, int32_t *keys_out,
                      int32_t *nkeys_out);
-int encode_plan_launch(const EncPlan &p, const float *x, int64_t x_stride, uint64_t seed, hipStream_t s);
+struct PlanArgs;   // scan_plan.h: the bucket lookup of the scan's PLAN phase, optionally run in encode_hash's epilogue
+// `lookup` (nullable): PlanArgs of the scan call this batch's keys go to (bucket_scan_plan_args), made ready for this launch by
+// encode_plan_fuse_lookup -- the scan call then runs NLSH_PHASE_PLAN_REST instead of NLSH_PHASE_PLAN.
+int encode_plan_launch(const EncPlan &p, const float *x, int64_t x_stride, uint64_t seed, hipStream_t s, const PlanArgs *lookup = nullptr);
+int encode_plan_fuse_lookup(EncPlan &p, PlanArgs &pa);
 
 }  // namespace nlsh

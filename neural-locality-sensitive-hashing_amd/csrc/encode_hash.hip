@@ -26,6 +26,7 @@
 #include <atomic>
 
 #include "encode_common.h"
+#include "scan_plan.h"
 
 namespace nlsh {
 
@@ -52,6 +53,8 @@ __device__ __forceinline__ void philox4x32_10(unsigned long long seed, uint32_t 
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// dynamic LDS a workgroup may ask for: the CU's 160 KB less the kernel's static variables (the lookup's two block counters, r06)
+constexpr size_t ENC_LDS_LIMIT = 160 * 1024 - 256;
 // Batches up to this many rows take the single-image 32-row form (2 x 256 CUs x 32 rows: every workgroup resident at once)
 #ifndef NLSH_ENC_BUILD_128
 #define NLSH_ENC_BUILD_128 1  // index-build launches: 1 = 128-row workgroups on one LDS image, 0 = 64-row workgroups on a ping-pong pair
@@ -88,7 +91,7 @@ __device__ __forceinline__ void philox4x32_10(unsigned long long seed, uint32_t 
 // workgroup on a CU adds 12.5 us (24.5 / 36.9 / 47.4 / 62.0 us at 1 / 2 / 3 / 4 per CU) where a second 32-row one adds 14 for twice
 // the rows.  It IS the shorter critical path while there is at most one workgroup per CU: batches of <= 4096 rows (24.5 vs 27.2 us).
 template <int RT, int NW, bool SINGLE, int MT = 1, int WPE = 1, bool H16 = false>  // MT: column tiles a wave may own in SINGLE mode (1: width <= 32*NW); WPE: waves per SIMD the registers must allow
-__global__ __launch_bounds__(NW * 64, WPE) void encode_hash_kernel(EncArgs a) {
+__global__ __launch_bounds__(NW * 64, WPE) void encode_hash_kernel(EncArgs a, PlanArgs pa) {
     constexpr int M = H16 ? 16 * RT : 32 * RT;   // H16: RT row tiles of 16 sharing every B fragment (shipped: RT = 1; RT = 3 measured and dropped in r05)
     static_assert(!H16 || SINGLE, "the 16-row-tile form runs on a single LDS image");
     constexpr int NTH = NW * 64;
@@ -437,8 +440,28 @@ __global__ __launch_bounds__(NW * 64, WPE) void encode_hash_kernel(EncArgs a) {
     ENC_STAMP(7);
     // ---- epilogue.  `out` holds z [M][33]; `in` is free.
     const int H = a.H;
+    const int NP = a.n_probes;
     float *zbuf = out;
     float *pbuf = SINGLE ? smem + M * 33 : in;  // Bernoulli probability [M][33]
+    // [M][n_probes] key table: over z (dead now) in the ping-pong form, behind z and p in the single image; behind it one 64-bit
+    // first-occurrence mask per row and (lookup fused, scan_plan.h) the coarse key table of the bucket search
+    int32_t *kbuf = reinterpret_cast<int32_t *>(SINGLE ? smem + 2 * M * 33 : out);
+    unsigned long long *fmask = reinterpret_cast<unsigned long long *>(kbuf + M * NP);
+    int32_t *coarse = reinterpret_cast<int32_t *>(fmask + M);
+    int32_t *cbuf = reinterpret_cast<int32_t *>(SINGLE ? smem : in);   // the rows' distinct keys, compacted (over z / p, dead by then)
+    __shared__ int plan_hits, plan_viol;
+    // r06: the bucket lookup of the scan's PLAN phase rides here when the caller asks for it (pa.enabled; wave-uniform): its coarse
+    // key table is requested now, lands in registers under the sigmoid pass and in LDS under the key pass
+    int32_t cpre[2] = {0, 0};
+    if (pa.enabled) {
+        if (tid < pa.nco) cpre[0] = pa.uniq[(long long)tid * pa.stride];
+        if (tid + NTH < pa.nco) cpre[1] = pa.uniq[(long long)(tid + NTH) * pa.stride];
+        if (tid == 0) { plan_hits = 0; plan_viol = 0; }
+        if (blockIdx.x == 0) plan_batch_init(pa, tid, NTH);
+        if (pa.prep_metric >= 0)   // the tiled schedule's padded / pre-normalised query copy of this workgroup's rows
+            for (int r = wave; r < M; r += NW)
+                if (row_base + r < a.n) prep_query(pa, row_base + r, lane);
+    }
     for (int e = tid; e < M * H; e += NTH) {
         int r = e / H, h = e - r * H;
         long long grow = row_base + r;
@@ -459,12 +482,8 @@ __global__ __launch_bounds__(NW * 64, WPE) void encode_hash_kernel(EncArgs a) {
     }
     __syncthreads();
     ENC_STAMP(8);
-    // (r02 measured a parallel form of this epilogue -- a thread per (row, probe, 4-bit word) OR-ing its bits into the code,
-    // de-duplication by a thread per (row, probe) with first-occurrence flags -- at 38.8 us per 10k queries against 37.5 us:
-    // four more passes and barriers cost what the idle threads had cost.)
-    // [M][n_probes] key table: over z (dead now) in the ping-pong form, behind z and p in the single image
-    int32_t *kbuf = reinterpret_cast<int32_t *>(SINGLE ? smem + 2 * M * 33 : out);
-    const int NP = a.n_probes;
+    // (r02 measured a parallel form of the key pass -- a thread per (row, probe, 4-bit word) OR-ing its bits into the code -- at
+    // 38.8 us per 10k queries against 37.5 us: four more passes and barriers cost what the idle threads had cost.)
     for (int e = tid; e < M * NP; e += NTH) {
         int r = e / NP, j = e - r * NP;
         long long grow = row_base + r;
@@ -488,9 +507,61 @@ __global__ __launch_bounds__(NW * 64, WPE) void encode_hash_kernel(EncArgs a) {
         kbuf[r * NP + j] = key;
         if (j == 0 && a.code_out) a.code_out[grow] = code;
     }
+    if (NP <= 64) {
+        if (tid < M) fmask[tid] = 0ull;
+        if (pa.enabled) {   // (z is dead: in the ping-pong form the table lies over it)
+            if (tid < pa.nco) coarse[tid] = cpre[0];
+            if (tid + NTH < pa.nco) coarse[tid + NTH] = cpre[1];
+        }
+    }
     __syncthreads();
     ENC_STAMP(9);
-    if (tid < M) {
+    if (NP <= 64) {
+        // Set semantics (utils.pyx:26-31), first-occurrence order, a thread per (row, probe) (r01-r05: one thread per ROW walked its
+        // probes with a nested loop -- 32 of 512 threads for 3.7 us of a 28-us workgroup): pass 1 marks the first occurrences in the
+        // row's 64-bit mask, pass 2 moves every first occurrence to its rank among them, pass 3 stores the row -- and, fused, looks
+        // every distinct key up (scan_plan.h).  Same table as the serial form, bit for bit.
+        for (int e = tid; e < M * NP; e += NTH) {
+            const int r = e / NP, j = e - r * NP;
+            const long long grow = row_base + r;
+            if (grow >= a.n || (j > 0 && grow >= a.n_multi_rows)) continue;
+            const int32_t key = kbuf[e];
+            bool first = true;
+            for (int t = 0; t < j; ++t) first &= kbuf[r * NP + t] != key;
+            if (first) atomicOr(&fmask[r], 1ull << j);
+        }
+        __syncthreads();
+        for (int e = tid; e < M * NP; e += NTH) {
+            const int r = e / NP, j = e - r * NP;
+            const long long grow = row_base + r;
+            if (grow >= a.n || (j > 0 && grow >= a.n_multi_rows)) continue;
+            const unsigned long long m = fmask[r];
+            if ((m >> j) & 1ull) cbuf[r * NP + __popcll(m & ((1ull << j) - 1ull))] = kbuf[e];
+        }
+        __syncthreads();
+        int nhit = 0, viol = 0;
+        for (int e = tid; e < M * NP; e += NTH) {
+            const int r = e / NP, j = e - r * NP;
+            const long long grow = row_base + r;
+            if (grow >= a.n) continue;
+            const int cnt = __popcll(fmask[r]);
+            const int32_t key = j < cnt ? cbuf[r * NP + j] : 0;
+            a.keys_out[grow * NP + j] = key;
+            if (j == 0) a.nkeys_out[grow] = cnt;
+            if (pa.enabled) {
+                if (j == 0) pa.tauq[grow] = KEY_NONE;        // running bound of the query
+                nhit += plan_pair(pa, coarse, grow * NP + j, key, j < cnt, viol) ? 1 : 0;
+            }
+        }
+        if (pa.enabled) {
+            // pairs this workgroup added to the counters (| violations): bscan_kernel holds the counters' sum against the sum of these
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { nhit += __shfl_xor(nhit, m); viol |= __shfl_xor(viol, m); }
+            if (lane == 0 && (nhit | viol)) { atomicAdd(&plan_hits, nhit); atomicOr(&plan_viol, viol); }
+            __syncthreads();
+            if (tid == 0) pa.hits[blockIdx.x] = plan_hits | plan_viol;
+        }
+    } else if (tid < M) {   // more than 64 probes (eval.py:148 sweeps to 100; never scanned in one call): the serial form
         const int r = tid;
         long long grow = row_base + r;
         if (grow < a.n) {
@@ -674,7 +745,7 @@ int encode_plan_fill(EncPlan &p, int64_t n, int n_layers, const int *dims, const
     p.form = ENC_FORM_SINGLE; p.grid = 0; p.lds = 0;
     if (n == 0) return NLSH_OK;
 
-    const size_t lds_limit = 160 * 1024;
+    const size_t lds_limit = ENC_LDS_LIMIT;
     int max_np = 0;  // widest hidden layer decides how many column tiles a wave owns
     for (int l = 0; l + 1 < n_layers; ++l) if (a.L[l].Np > max_np) max_np = a.L[l].Np;
     // Query-sized batches (and encoders too wide for two 64-row images) run 32-row workgroups on a SINGLE LDS image;
@@ -723,23 +794,60 @@ static int allow_lds(int form, const void *fn) {
     int dev = 0;
     NLSH_CHECK_HIP(hipGetDevice(&dev));
     if (dev >= 0 && dev < 16 && (done[dev].load(std::memory_order_acquire) >> form) & 1u) return NLSH_OK;
-    NLSH_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    NLSH_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ENC_LDS_LIMIT));
     if (dev >= 0 && dev < 16) done[dev].fetch_or(1u << form, std::memory_order_release);
     return NLSH_OK;
 }
 
-int encode_plan_launch(const EncPlan &p, const float *x, int64_t x_stride, uint64_t seed, hipStream_t s) {
+// rows per workgroup of a kernel form
+static int form_rows(int form) {
+    return form == ENC_FORM_H16 ? 16 : form == ENC_FORM_BUILD128 ? 128 : form == ENC_FORM_PINGPONG ? 64 : 32;
+}
+
+// The bucket lookup of the scan's PLAN phase in this launch's epilogue (scan_plan.h): sizes the coarse key table for the LDS the form
+// has behind its key table -- growing the rows' stride when an encoder is so narrow that fewer than 256 entries would fit -- and
+// returns the workgroups of the launch (= entries of `hits` the look-back verdict of bscan_kernel sums).
+int encode_plan_fuse_lookup(EncPlan &p, PlanArgs &pa) {
+    NLSH_REQUIRE(p.a.n == pa.Q && p.a.n_probes == pa.P, NLSH_E_INVALID, "encode_hash + lookup: the encode makes a [%lld, %d] key table, the scan expects [%lld, %d]",
+                 (long long)p.a.n, p.a.n_probes, (long long)pa.Q, pa.P);
+    NLSH_REQUIRE(pa.P <= 64, NLSH_E_UNSUPPORTED, "encode_hash + lookup: n_probes=%d > 64", pa.P);
+    if (p.a.n == 0) return NLSH_OK;
+    const int M = form_rows(p.form), NP = p.a.n_probes;
+    const bool pingpong = p.form == ENC_FORM_PINGPONG;
+    const int used = (pingpong ? 0 : 2 * 33) + NP + 2;            // floats per row in front of the coarse table (z, p | keys, mask)
+    int cap = M * (p.a.S - used);
+    const int want = pa.nb < 256 ? (pa.nb > 0 ? pa.nb : 1) : 256;
+    if (cap < want) {
+        p.a.S = round_up(used + (want + M - 1) / M, 8) + 4;       // S / 4 stays odd (conflict-free A-fragment reads)
+        p.lds = (size_t)(pingpong ? 2 : 1) * M * p.a.S * 4;
+        NLSH_REQUIRE(p.lds <= ENC_LDS_LIMIT, NLSH_E_UNSUPPORTED, "encode_hash + lookup: %zu B of LDS", p.lds);
+        cap = M * (p.a.S - used);
+    }
+    plan_coarse(pa, cap < 1024 ? cap : 1024);                      // two entries per thread of the 512 at most
+    pa.enabled = 1;
+    return NLSH_OK;
+}
+
+int encode_plan_launch(const EncPlan &p, const float *x, int64_t x_stride, uint64_t seed, hipStream_t s, const PlanArgs *lookup) {
     if (p.a.n == 0) return NLSH_OK;
     NLSH_REQUIRE(x != nullptr, NLSH_E_INVALID, "encode_hash: null pointer");
     NLSH_REQUIRE(x_stride >= p.a.L[0].K, NLSH_E_INVALID, "encode_hash: x_stride %lld < d %d", (long long)x_stride, p.a.L[0].K);
     EncArgs a = p.a;
     a.x = x; a.x_stride = x_stride; a.seed = seed;
+    PlanArgs pa;
+    if (lookup) {
+        pa = *lookup;
+        pa.queries = x; pa.q_stride = x_stride;   // the batch itself (the padded query copy is made from it)
+    } else {
+        pa = PlanArgs{};
+        pa.enabled = 0; pa.prep_metric = -1;
+    }
 #define NLSH_ENC_LAUNCH(FORM, ...)                                                                 \
     case FORM: {                                                                                   \
         auto *fn = encode_hash_kernel<__VA_ARGS__>;                                                \
         int rc = allow_lds(FORM, (const void *)fn);                                                \
         if (rc != NLSH_OK) return rc;                                                              \
-        hipLaunchKernelGGL(fn, dim3(p.grid), dim3(512), p.lds, s, a);                              \
+        hipLaunchKernelGGL(fn, dim3(p.grid), dim3(512), p.lds, s, a, pa);                          \
     } break;
     switch (p.form) {
         NLSH_ENC_LAUNCH(ENC_FORM_H16, 1, 8, true, 2, 1, true)

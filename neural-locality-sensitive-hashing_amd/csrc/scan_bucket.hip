@@ -12,16 +12,18 @@
 //                         tile, queries arrive as scalar loads, no cross-lane traffic, k-ordered fmaf chain
 //                         (bit-identical to the oracle), selection by bisection instead of insertion.
 //
-// Per batch, all on the caller's stream, no host round trip:
-//   bplan    thread/(query,probe): binary search key -> bucket; count pairs per bucket; C_q
-//   bscan    thread/bucket: block scan + one atomic per block -> disjoint pair/task ranges;
-//            task = (group of <= QB pairs, segment of <= seg rows), segment-major ids
-//   bscatter thread/(query,probe): claim a slot in the bucket's query list
-//            (tiled, cosine / folded L2 / d % 4 != 0 only: extra workgroups of the same launch write the padded / pre-normalised query copy)
+// Per batch, all on the caller's stream, no host round trip (r06: five launches with the lookup fused into encode_hash, six without):
+//   bplan    thread/(query,probe): binary search key -> bucket -> cell; the pair takes its slot in the cell's list (atomicAdd);
+//            scan_plan.h -- in the epilogue of encode_hash_kernel when the keys come from there, bplan_kernel for caller-supplied keys
+//            (tiled, cosine / folded L2 / d % 4 != 0 only: the padded / pre-normalised query copy is written by the same launch)
+//   bscan    thread/cell: reads AND resets the cell's pair counter; block scan + decoupled look-back over the per-block totals ->
+//            disjoint pair/task ranges; task = (group of <= QB pairs, segment of <= seg rows), segment-major ids
+//   bscatter thread/(query,probe): the pair's record into its cell's query list and its tasks' slot records (no atomics)
 //   bscan2 | bscan3: partial top-k per (task, query)
 //   bmerge   wave/query: merge the partial lists of its (probe, segment) pairs -> final top-k
 // Results do not depend on slot/task order: every list is merged with the (distance, id) comparator.
 #include "scan_common.h"
+#include "scan_plan.h"
 
 // Diagnostic build only (make EXTRA=-DNLSH_SCAN_TRACE, tools/scan_trace.py): wave 0 of every bscan3 workgroup
 // leaves its phase durations (100 MHz wall_clock64 ticks) in g_scan_trace; the shipped library has neither.
@@ -116,18 +118,19 @@ struct BArgs {
     uint64_t *out_keys;
     int32_t *out_ncand;
     int32_t *status;
-    int32_t *pbkt, *inv_q, *bcount, *pairoff, *taskoff, *bgroups, *counters;   // bcount / pairoff / taskoff / bgroups are per CELL
+    int32_t *inv_q, *bcount;   // bcount: per CELL
+    int4 *ppair;    // [Q*P] what the lookup left per (query, probe) pair (scan_plan.h): {cell, slot in the cell's list, bucket rows, first row inside the cell}
+    int4 *cellrec;  // [nc] per cell, written by bscan: {first pair of its list, first task, query groups, 0}
     int4 *prec;  // [Q*P] per (query, probe): {first task of its query group, slot in the group, bucket rows, query groups}; .z = 0: no bucket
     int4 *task;
     int2 *task_qr;     // tiled schedule: [max_tasks][16] {query id, row range lo | hi << 16} of every (task, slot): the task's group's slice of
                        // inv_q, repeated per row segment, and the rows of the query's bucket inside the task's rows (a whole segment of a
                        // big bucket; the bucket's slice of a shared window).  ONE 8-byte record: one store in bscatter, one load in the scan
-    int32_t *pcell;    // [Q*P] cell of every (query, probe) pair's bucket (bplan looked it up for the counter: bscatter need not again)
     uint64_t *partial;
     long long max_tasks;
     const int32_t *border;     // [nc] schedule order of the cells (largest first) or nullptr = CSR order
-    int32_t *btot;             // [3 * blocks of bscan] per-block (pairs, tasks, negative counters) totals
-    int32_t *hits;             // [blocks of bplan] (query, probe) pairs each bplan block found a bucket for
+    unsigned long long *lookback;   // [blocks of bscan] per-block (pairs, tasks, negative counter seen) totals + ready bit, zeroed by the plan launch
+    int32_t *hits;             // [blocks of the plan launch] (query, probe) pairs each block counted | PLAN_VIOL_* flags
     unsigned long long *tauq;  // [Q] running upper bound of each query's k-th best key (atomicMin), KEY_NONE-initialised
     const float *qpad;  // tiled variant: queries padded to d4p*4 floats (L2: pad = -eps; cosine: pre-normalised, pad = 0)
     float *qpad_w;      // same buffer, writable (prep_query); qpad aliases `queries` when no padding/normalisation is needed
@@ -135,199 +138,178 @@ struct BArgs {
     int d4p;
 };
 
-// Padded / pre-normalised copy of one query for the tiled schedule (one wavefront per query): L2 pads with -eps ((q - 0) + eps == 0 on
-// padding), the folded L2 form stores q + eps, cosine stores x1 / max(||x1||, 1e-8) as cosine_similarity does.  Runs as extra
-// workgroups of bplan_kernel (r04: its own launch cost the cosine / folded / d % 4 != 0 configurations ~5 us per batch for 1 us of work).
-__device__ __forceinline__ void prep_query(const BArgs &a, int metric, long long q, int lane) {
-    const float *qp = a.queries + q * a.q_stride;
-    float *dst = a.qpad_w + q * a.qpad_stride;
-    const int n = a.d4p * 4;
-    if (metric == NLSH_METRIC_L2_EPS) {
-        for (int e = lane; e < n; e += 64) dst[e] = e < a.d ? qp[e] : -1e-6f;  // (q - 0) + eps == 0 on padding
-    } else if (metric == NLSH_METRIC_L2_EPS_FOLDED) {
-        for (int e = lane; e < n; e += 64) dst[e] = e < a.d ? qp[e] + 1e-6f : 0.0f;   // eps folded into the query: (q + eps) - c; 0 - 0 on padding
-    } else {
-        float ss = 0.0f;
-        for (int e = lane; e < a.d; e += 64) ss = fmaf(qp[e], qp[e], ss);
-        for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
-        const float nrm = fmaxf(sqrtf(ss), 1e-8f);  // x1 / max(||x1||, eps), as cosine_similarity does
-        for (int e = lane; e < n; e += 64) dst[e] = e < a.d ? qp[e] / nrm : 0.0f;
-    }
-}
-
-// Bucket lookup of every (query, probe): binary search of the key in uniq[nb].  The first ~10 of its ~13 steps run on a
-// coarse table in LDS (every `stride`-th key, <= 1024 entries, loaded once per workgroup), the last log2(stride) on the
-// stride-long run in global memory: 3-4 dependent global loads per thread instead of 13.
+// Bucket lookup of every (query, probe) of a CALLER-SUPPLIED key table (keys from encode_hash are looked up in its own epilogue):
+// scan_plan.h.  The coarse table (every `stride`-th key, <= 1024 entries) is loaded once per workgroup.
 // Workgroups past `plan_blocks` prepare the tiled schedule's query copy instead (prep_metric >= 0), four queries each.
-__global__ __launch_bounds__(256) void bplan_kernel(BArgs a, int stride, unsigned plan_blocks, int prep_metric) {
+__global__ __launch_bounds__(256) void bplan_kernel(PlanArgs a, unsigned plan_blocks) {
     __shared__ int32_t coarse[1024];
-    __shared__ int whits[4];
+    __shared__ int whits[4], wviol[4];
     if (blockIdx.x >= plan_blocks) {   // uniform per workgroup: no barrier below is reached by these
         const long long q = (long long)(blockIdx.x - plan_blocks) * 4 + (threadIdx.x >> 6);
-        if (q < a.Q) prep_query(a, prep_metric, q, threadIdx.x & 63);
+        if (q < a.Q) prep_query(a, q, threadIdx.x & 63);
         return;
     }
-    const int nco = (a.nb + stride - 1) / stride;
-    for (int i = threadIdx.x; i < nco; i += 256) coarse[i] = a.uniq[(long long)i * stride];
+    for (int i = threadIdx.x; i < a.nco; i += 256) coarse[i] = a.uniq[(long long)i * a.stride];
+    if (blockIdx.x == 0) plan_batch_init(a, threadIdx.x, 256);   // per-batch initialisation rides along (no separate launch)
     __syncthreads();
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx == 0) { a.status[0] = 0; a.status[1] = 0; }   // per-batch initialisation rides along (no separate launch)
-    int b = -1, cell = -1;
+    bool hit = false;
+    int viol = 0;
     if (idx < a.Q * a.P) {
         const long long q = idx / a.P;
         const int p = (int)(idx - q * a.P);
         if (p == 0) a.tauq[q] = KEY_NONE;        // running bound of the query
-        int nk = a.nkeys[q];
+        int nk = a.qnkeys[q];
         nk = nk < 0 ? 0 : (nk > a.P ? a.P : nk);
-        if (p < nk) {
-            const int32_t key = a.qkeys[idx];
+        int32_t key = 0;
+        bool live = p < nk;
+        if (live) {
+            key = a.qkeys[idx];
             // a query's keys are a SET (nlsh/utils.pyx:27-31): a repeated key probes its bucket once.  encode_hash never
             // emits one; a C caller's table might, and the selection-based merges assume distinct (distance, id) keys.
-            bool dup = false;
-            for (int pp = 0; pp < p; ++pp) dup |= a.qkeys[idx - p + pp] == key;
-            int lo = 0, hi = dup ? 0 : nco;
-            while (lo < hi) {  // first coarse entry > key
-                const int mid = (lo + hi) >> 1;
-                if (coarse[mid] <= key) lo = mid + 1; else hi = mid;
-            }
-            if (lo > 0) {  // the key, if present, lies in the run that starts at coarse entry lo-1
-                lo = (lo - 1) * stride;
-                hi = min(a.nb, lo + stride);
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (a.uniq[mid] < key) lo = mid + 1; else hi = mid;
-                }
-                if (lo < a.nb && a.uniq[lo] == key) {  // unknown key = empty bucket (indexer.py:61,68)
-                    const int sz = a.offsets[lo + 1] - a.offsets[lo];
-                    if (sz > 0) {
-                        b = lo;
-                        cell = a.cell_of ? a.cell_of[lo] : lo;
-                        atomicAdd(&a.bcount[cell], 1);
-                    }
-                }
-            }
+            for (int pp = 0; pp < p; ++pp) live &= a.qkeys[idx - p + pp] != key;
         }
-        a.pbkt[idx] = b;
-        a.pcell[idx] = cell;
+        hit = plan_pair(a, coarse, idx, key, live, viol);
     }
     // pairs this block added to the counters: bscan_kernel holds the counters' sum against the sum of these, which is how
     // a workspace head that was not zero on entry (workspace contract, nlsh_hip.h) is caught instead of trusted
-    const unsigned long long m = __ballot(b >= 0);
-    if ((threadIdx.x & 63) == 0) whits[threadIdx.x >> 6] = __popcll(m);
+    const unsigned long long m = __ballot(hit);
+    const unsigned long long v1 = __ballot(viol & PLAN_VIOL_COUNTER), v2 = __ballot(viol & PLAN_VIOL_CELLS);
+    if ((threadIdx.x & 63) == 0) {
+        whits[threadIdx.x >> 6] = __popcll(m);
+        wviol[threadIdx.x >> 6] = (v1 ? PLAN_VIOL_COUNTER : 0) | (v2 ? PLAN_VIOL_CELLS : 0);
+    }
     __syncthreads();
-    if (threadIdx.x == 0) a.hits[blockIdx.x] = whits[0] + whits[1] + whits[2] + whits[3];
+    if (threadIdx.x == 0) a.hits[blockIdx.x] = (whits[0] + whits[1] + whits[2] + whits[3]) | wviol[0] | wviol[1] | wviol[2] | wviol[3];
 }
 
-__device__ __forceinline__ int block_excl_scan(int v, int *wsum, int *total) {
+// exclusive scan of a 64-bit value over the 256 threads of a block (two packed 32-bit sums scanned together: the low word must not
+// carry into the high one, which the callers' ranges guarantee: low = pairs <= Q * P < 2^31)
+__device__ __forceinline__ unsigned long long block_excl_scan64(unsigned long long v, unsigned long long *wsum, unsigned long long *total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int incl = v;
+    unsigned long long incl = v;
     for (int m = 1; m < 64; m <<= 1) {
-        int t = __shfl_up(incl, m);
-        if (lane >= m) incl += t;
+        const unsigned lo = __shfl_up((unsigned)incl, m), hi = __shfl_up((unsigned)(incl >> 32), m);
+        if (lane >= m) incl += ((unsigned long long)hi << 32) | lo;
     }
     __syncthreads();
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    int woff = 0;
+    unsigned long long woff = 0;
     for (int w = 0; w < wave; ++w) woff += wsum[w];
     *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     return woff + incl - v;
 }
 
-// Tasks are numbered in SCHEDULE order: bucket `border[i]` (buckets by descending size, fixed at index build)
+// Tasks are numbered in SCHEDULE order: cell `border[i]` (cells by descending size, fixed at index build)
 // is handled by thread i, so the heavy (segment x query-group) tasks of the big buckets get the low ids and are
 // dispatched first, the single small tasks of the small buckets last: the kernel no longer ends on a tail of
 // 40-us tasks started in its last microseconds (measured: machine full until 370 us, drained until 440 us).
-// Numbering is deterministic: bcount_kernel leaves per-block totals, bscan_kernel sums the totals of the
-// blocks before it (no atomics, no dependence on block timing).
-__device__ __forceinline__ void bucket_task_counts(const BArgs &a, int i, int &b, int &m, int &s, int &ns, int &ng) {
-    b = a.border ? a.border[i] : i;   // a CELL (a bucket when the index has no cells)
-    m = a.bcount[b];
-    s = a.coffsets[b + 1] - a.coffsets[b];
-    ns = (s + a.seg - 1) / a.seg;
-    ng = (m + a.QB - 1) / a.QB;
+// Numbering is deterministic (no dependence on block timing): block j publishes its totals, block i sums the
+// totals of the blocks before it.
+//
+// r06: ONE launch (r02-r05: bcount_kernel left the per-block totals, a second launch summed them: a dependent launch costs ~4.5 us
+// on this part whatever it does).  Decoupled look-back without the chain: a block publishes its OWN totals -- they depend on nothing
+// but its own 256 counters -- as one 64-bit word {tasks : 32 | pairs : 30 | negative counter seen : 1 | ready : 1} with a
+// device-scope store, then thread t waits for the words of blocks t, t + 256, ... < blockIdx.x and the block adds them up.  Blocks
+// are dispatched in index order and a block only ever waits for LOWER indices, which wait for nothing unfinished: the lowest
+// unfinished block always runs, so the wait cannot deadlock whatever the grid size.  The slots are zeroed by the plan launch in
+// front of this one (plan_batch_init).  Device-scope (sc1) accesses to the slots only: no fence, no L2 write-back (r02 measured an
+// in-kernel grid barrier with agent-scope fences at 127 us -- each writes back an XCD's L2).
+//
+// The pair counters are READ AND RESET here (thread per cell): the slot of every pair was fixed when the lookup incremented the
+// counter (scan_plan.h), so nobody needs the counts after this kernel, and the head of the workspace is zero again for the next
+// batch (workspace contract) without the scatter step's atomicSub of r01-r05.
+//
+// status[1] = 2: the pair counters were not zero when the batch's lookup started (an uninitialised buffer, one lent to another
+// schedule).  The LAST block knows every total: the counters must sum to the pairs the lookup counted this batch, none may be
+// negative and no pair may have drawn a negative slot.  On a violation status[0] = 0 -- the scan launches no task -- and bscatter,
+// which starts after this kernel, drops every pair: nothing is ever addressed through a stale count (negative counts are clamped
+// to zero before they enter a prefix; descriptors are written inside the table only; the pair lists are only written by bscatter).
+// The facade turns the flag into NLSH_E_WORKSPACE.  status[1] = 3: the lookup refused a pair of a foreign cell layout (scan_plan.h).
+constexpr unsigned long long LB_READY = 1ull, LB_NEG = 2ull;
+__device__ __forceinline__ void lookback_publish(unsigned long long *slot, unsigned long long v) {
+    __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long lookback_wait(unsigned long long *slot) {
+    unsigned long long v;
+    do { v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(v & LB_READY));
+    return v;
 }
 
-__global__ __launch_bounds__(256) void bcount_kernel(BArgs a) {
-    __shared__ int wsum[4];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    int b, m = 0, s, ns = 0, ng = 0;
-    if (i < a.nc) bucket_task_counts(a, i, b, m, s, ns, ng);
-    int tot_m, tot_t, tot_neg;
-    block_excl_scan(m, wsum, &tot_m);
-    block_excl_scan(ng * ns, wsum, &tot_t);
-    block_excl_scan(m < 0 ? 1 : 0, wsum, &tot_neg);
-    if (threadIdx.x == 0) {
-        a.btot[3 * blockIdx.x] = tot_m;
-        a.btot[3 * blockIdx.x + 1] = tot_t;
-        a.btot[3 * blockIdx.x + 2] = tot_neg;
-    }
-}
-
-// status[1] = 2: the per-bucket pair counters at the head of the workspace were not zero when the batch's PLAN phase
-// started (an uninitialised buffer, one lent to another schedule, a call aborted between bplan and bscatter).  Every block
-// derives the verdict from the same numbers -- the counters must sum to the pairs bplan counted this batch and none may be
-// negative --, so either all of them lay out tasks or none does: a poisoned batch gets NO task, bscatter writes empty
-// records and the merge returns empty lists; nothing is ever addressed through a stale count.  The facade turns the flag
-// into NLSH_E_WORKSPACE.
 __global__ __launch_bounds__(256) void bscan_kernel(BArgs a, int plan_blocks) {
-    __shared__ int wsum[4];
-    __shared__ int base_m, base_t, chk_s, neg_s;
+    __shared__ unsigned long long wsum[4];
+    __shared__ unsigned long long base_s;
+    __shared__ int neg_s, flags_s;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (threadIdx.x == 0) { chk_s = 0; neg_s = 0; }
-    __syncthreads();
-    int all_m = 0, all_neg = 0, all_hits = 0;
-    for (int j = threadIdx.x; j < (int)gridDim.x; j += 256) {
-        all_m += a.btot[3 * j];
-        all_neg += a.btot[3 * j + 2];
-    }
-    for (int j = threadIdx.x; j < plan_blocks; j += 256) all_hits += a.hits[j];
-    // (sum of the counters) - (pairs bplan counted) and the number of negative counters, summed over the block with LDS atomics
-    // (one barrier; as two more block scans this check cost the kernel 1.8 us)
-    if (all_m != all_hits) atomicAdd(&chk_s, all_m - all_hits);
-    if (all_neg) atomicAdd(&neg_s, all_neg);
-    __syncthreads();
-    const bool bad = chk_s != 0 || neg_s != 0;
-    int dummy;
+    if (threadIdx.x == 0) { neg_s = 0; flags_s = 0; }
     int b = 0, m = 0, s = 0, ns = 0, ng = 0;
+    bool neg = false;
     if (i < a.nc) {
-        bucket_task_counts(a, i, b, m, s, ns, ng);
-        if (bad) { m = 0; ng = 0; }
-        a.bgroups[b] = ng;
+        b = a.border ? a.border[i] : i;   // a CELL (a bucket when the index has no cells)
+        m = a.bcount[b];
+        if (m != 0) a.bcount[b] = 0;      // handed back: zero again for the next batch
+        neg = m < 0;
+        m = neg ? 0 : m;                  // a stale negative count enters no prefix (the batch is refused below)
+        s = a.coffsets[b + 1] - a.coffsets[b];
+        ns = (s + a.seg - 1) / a.seg;
+        ng = (m + a.QB - 1) / a.QB;
     }
     const int nt = ng * ns;
-    // totals of the blocks before this one (and, in the last block, of all blocks -> status[0])
-    int pm = 0, pt = 0;
+    unsigned long long tot;
+    const unsigned long long ex = block_excl_scan64(((unsigned long long)(unsigned)nt << 32) | (unsigned)m, wsum, &tot);   // (barriers inside: neg_s is initialised)
+    if (neg) neg_s = 1;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        lookback_publish(a.lookback + blockIdx.x, (tot & 0xFFFFFFFF00000000ull) | ((tot & 0x3FFFFFFFull) << 2) | (neg_s ? LB_NEG : 0ull) | LB_READY);
+    // totals of the blocks before this one
+    unsigned long long prev = 0;
+    int pneg = 0;
     for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) {
-        pm += a.btot[3 * j];
-        pt += a.btot[3 * j + 1];
+        const unsigned long long v = lookback_wait(a.lookback + j);
+        prev += (v & 0xFFFFFFFF00000000ull) | ((v >> 2) & 0x3FFFFFFFull);
+        pneg |= (v & LB_NEG) ? 1 : 0;
     }
-    int tot_m, tot_t;
-    const int ex_m = block_excl_scan(m, wsum, &tot_m);
-    const int ex_t = block_excl_scan(nt, wsum, &tot_t);
-    block_excl_scan(pm, wsum, &dummy);
-    if (threadIdx.x == 0) base_m = dummy;
-    block_excl_scan(pt, wsum, &dummy);
-    if (threadIdx.x == 0) {
-        base_t = dummy;
-        if (blockIdx.x == gridDim.x - 1) {
-            a.status[0] = bad ? 0 : dummy + tot_t;  // tasks needed (may exceed max_tasks: the caller retries)
-            if (bad) a.status[1] = 2;
+    {
+        unsigned long long ptot;
+        block_excl_scan64(prev, wsum, &ptot);
+        if (threadIdx.x == 0) base_s = ptot;
+        if (pneg) neg_s = 1;
+    }
+    const bool last_block = blockIdx.x == gridDim.x - 1;
+    if (last_block) {   // the verdict: every total is known here
+        int hsum = 0, hflags = 0;
+        for (int j = threadIdx.x; j < plan_blocks; j += 256) {
+            const int h = a.hits[j];
+            hsum += h & PLAN_HITS_MASK;
+            hflags |= h & ~PLAN_HITS_MASK;
+        }
+        unsigned long long htot;
+        __syncthreads();
+        block_excl_scan64((unsigned long long)(unsigned)hsum, wsum, &htot);
+        if (hflags) atomicOr(&flags_s, hflags);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long all = base_s + tot;
+            const bool bad = (all & 0xFFFFFFFFull) != htot || neg_s != 0 || (flags_s & PLAN_VIOL_COUNTER);
+            a.status[0] = bad ? 0 : (int)(all >> 32);   // tasks needed (may exceed max_tasks: the caller retries)
+            a.status[1] = bad ? 2 : ((flags_s & PLAN_VIOL_CELLS) ? 3 : 0);
         }
     }
-    // A bucket's descriptors are written by its own thread (writing a block's tasks with all its threads, one task per thread and
+    __syncthreads();
+    // A cell's descriptors are written by its own thread (writing a block's tasks with all its threads, one task per thread and
     // round, measured 15.6 us against 9.5 us on the SIFT1M-shaped batch) -- unless it has more than HEAVY of them: a 180 k-row
     // bucket probed by thousands of queries (Deep100M-shaped: 707 segments x hundreds of query groups) is 10^5 descriptors, and one
-    // thread writing them made this kernel 1.0 ms of a 37-ms step (r03).  Heavy buckets are queued in LDS and written by the whole block.
+    // thread writing them made this kernel 1.0 ms of a 37-ms step (r03).  Heavy cells are queued in LDS and written by the whole block.
     constexpr int HEAVY = 256, HEAVY_SLOTS = 256;
     __shared__ int heavy_n;
-    __shared__ int heavy_b[HEAVY_SLOTS][6];   // po, to, ng, nt, m, bucket (row0 and size are re-read)
+    __shared__ int heavy_b[HEAVY_SLOTS][6];   // po, to, ng, nt, m, cell (row0 and size are re-read)
     if (threadIdx.x == 0) heavy_n = 0;
     __syncthreads();
-    if (i < a.nc && !bad) {
-        const int po = base_m + ex_m, to = base_t + ex_t;
-        a.pairoff[b] = po;
-        a.taskoff[b] = to;
+    if (i < a.nc) {
+        const unsigned long long off = base_s + ex;
+        const int po = (int)(off & 0xFFFFFFFFull), to = (int)(off >> 32);
+        a.cellrec[b] = make_int4(po, to, ng, 0);
         if (nt > HEAVY) {
             const int slot = atomicAdd(&heavy_n, 1);   // <= 256 threads, so a slot always exists
             heavy_b[slot][0] = po; heavy_b[slot][1] = to; heavy_b[slot][2] = ng; heavy_b[slot][3] = nt; heavy_b[slot][4] = m; heavy_b[slot][5] = b;
@@ -356,43 +338,31 @@ __global__ __launch_bounds__(256) void bscan_kernel(BArgs a, int plan_blocks) {
     }
 }
 
+// Every counted pair into its cell's query list and its tasks' slot records.  r06: no atomics and one dependent load level -- the
+// lookup left {cell, slot, bucket rows, first row inside the cell} per pair (scan_plan.h) and bscan one {first pair, first task,
+// query groups} record per cell (r01-r05: atomicSub on the cell's counter for the slot, then five loads behind it).
 __global__ __launch_bounds__(256) void bscatter_kernel(BArgs a) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= a.Q * a.P) return;
-    const int b = a.pbkt[idx];
-    if (b < 0 || a.status[1] == 2) {   // no bucket, or a poisoned workspace (bscan_kernel): nothing is addressed through the counters
+    const int4 pp = a.ppair[idx];
+    if (pp.x < 0 || a.status[1] == 2) {   // no bucket, or a poisoned workspace (bscan_kernel): nothing is addressed through the counters
         a.prec[idx] = make_int4(0, 0, 0, 0);
         return;
     }
-    const int c = a.pcell[idx];
-    const int rel = atomicSub(&a.bcount[c], 1) - 1;  // slot of this query in the cell's pair list
-    if (rel < 0) {   // the counter started below zero-plus-this-batch's-pairs: a stale negative count (workspace contract); no slot exists
-        a.status[1] = 2;
-        a.prec[idx] = make_int4(0, 0, 0, 0);
-        return;
-    }
-    a.inv_q[a.pairoff[c] + rel] = (int32_t)(idx / a.P);
+    const int rel = pp.y, size = pp.z, lo0 = pp.w;   // slot in the cell's pair list; rows of the BUCKET; its first row inside the cell (0 for a bucket that is its own cell)
+    const int4 cr = a.cellrec[pp.x];
+    a.inv_q[cr.x + rel] = (int32_t)(idx / a.P);
     // what bmerge needs to find this probe's partial lists, resolved here so that it has one load level less:
-    // task of (segment si, group gi) = taskoff + si * ngroups + gi
+    // task of (segment si, group gi) = first task of the cell + si * ngroups + gi
     const int gi = rel / a.QB;
     // `size` = rows of the BUCKET: the query's candidate count, and (size + seg - 1) / seg = its partial lists -- one per row segment of
-    // a big bucket, exactly one for a bucket inside a shared window (window_rows <= seg)
-    const int row0 = a.offsets[b], size = a.offsets[b + 1] - row0;
-    // A bucket that is only PART of its cell lives in a shared window, and a shared window must fit one segment (nlsh_build_cells:
-    // window_rows <= 256 = the segment, static_assert below): this kernel takes the bucket's partial-list count from its own size and
-    // clamps its row range to the segment.  Cells from elsewhere that break the rule are refused (status[1] = 3), never scanned short.
-    if (a.cell_of && size < a.coffsets[c + 1] - a.coffsets[c] && a.coffsets[c + 1] - a.coffsets[c] > a.seg) {
-        a.status[1] = 3;
-        a.prec[idx] = make_int4(0, 0, 0, 0);
-        return;
-    }
-    const int t0 = a.taskoff[c] + gi, ng = a.bgroups[c];
+    // a big bucket, exactly one for a bucket inside a shared window (window_rows <= seg; the lookup refuses cells that break this)
+    const int t0 = cr.y + gi, ng = cr.z;
     a.prec[idx] = make_int4(t0, rel - gi * a.QB, size, ng);
     if (a.task_qr) {
         // the tiled scan reads a task's query ids from the task's own record (address known from the task id alone: the
         // ids arrive with the descriptor instead of one dependent round trip later); one copy per row segment
         const int ns = (size + a.seg - 1) / a.seg;
-        const int lo0 = row0 - a.coffsets[c];   // first row of the bucket inside its cell (0 for a bucket that is its own cell)
         for (int si = 0; si < ns; ++si) {
             const long long tt = (long long)t0 + (long long)si * ng;
             if (tt >= a.max_tasks) break;
@@ -1314,20 +1284,13 @@ __global__ __launch_bounds__(64 * NW, NLSH_TILED_MIN_WAVES) void bscan3_kernel(B
     tiled_task_body<METRIC, QW, NW, TPS>(a, tile, t, desc, qr_all, tid, lane, wave, ts_entry);
 }
 
+// (r01-r05 re-checked here that every pair counter was back at zero; since r06 bscan_kernel resets the counters itself and its
+// verdict covers every way a stale count can enter a batch -- positive ones through the sum, negative ones directly.)
 __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
-    // Every pair counter is back at zero once the scatter step has run -- unless it did not start from zero (workspace
-    // contract).  The PLAN phase's sum check catches stale counts that change the totals (those would overrun the pair
-    // lists); this per-bucket check catches the rest (stale counts that cancel in the sum mis-size individual lists: every
-    // access stays in bounds -- clamped query ids, guarded slots -- but the lists are wrong), so a violated contract is
-    // ALWAYS reported (status[1] = 2), never a silently wrong result.
-    // (the counters are requested first and looked at last: the check must not sit in front of the merge's own dependent loads)
-    int stale = 0;
-    for (long long b = (long long)blockIdx.x * 256 + threadIdx.x; b < a.nb; b += (long long)gridDim.x * 256) stale |= a.bcount[b];
     const int lane = threadIdx.x & 63;
     const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     __shared__ uint64_t scratch[4][64];
     if (q < a.Q) merge_query(a, q, lane, scratch[threadIdx.x >> 6]);
-    if (stale != 0) a.status[1] = 2;
 }
 
 #ifndef NLSH_TILED_QB
@@ -1343,24 +1306,27 @@ constexpr int TILED_TPS = NLSH_TILED_TPS;  // 64-row tiles per task of the tiled
 static_assert(64 * TILED_TPS >= 256, "the tiled schedule's segment must hold the widest row window nlsh_build_cells accepts (256 rows)");
 
 struct BWs {
-    size_t pbkt, prec, inv_q, bcount, pairoff, taskoff, bgroups, counters, btot, hits, task, task_qr, pcell, partial, qpad, tauq, total;
+    size_t ppair, prec, inv_q, bcount, cellrec, lookback, hits, task, task_qr, partial, qpad, tauq, total;
 };
+// blocks of the launch that does the lookup: bplan_kernel's 256 pairs per block, or encode_hash's workgroups (>= 16 rows each)
+static inline long long plan_blocks_max(long long Q, int P) {
+    const long long a = (Q * P + 255) / 256, b = (Q + 15) / 16;
+    return (a > b ? a : b) + 1;
+}
 static void blayout(long long Q, int P, int k, long long max_tasks, long long nb, int d, bool tiled, BWs *w) {
     size_t o = 0;
     const size_t qp = (size_t)Q * P * 4, nb4 = (size_t)(nb > 0 ? nb : 1) * 4;
     w->bcount = o;   o += ws_align(nb4);   // first, at an offset that does not depend on the batch: ZERO between calls (workspace contract)
-    w->pbkt = o;     o += ws_align(qp);
+    w->ppair = o;    o += ws_align(qp * 4);
     w->prec = o;     o += ws_align(qp * 4);
     w->inv_q = o;    o += ws_align(qp);
-    w->pairoff = o;  o += ws_align(nb4);
-    w->taskoff = o;  o += ws_align(nb4);
-    w->bgroups = o;  o += ws_align(nb4);
-    w->counters = o; o += ws_align(64);
-    w->btot = o;     o += ws_align((size_t)((nb + 255) / 256 + 1) * 12);
-    w->hits = o;     o += ws_align((size_t)((Q * P + 255) / 256 + 1) * 4);
+    w->cellrec = o;  o += ws_align(nb4 * 4);
+    w->lookback = o; o += ws_align((size_t)((nb + 255) / 256 + 1) * 8);
+    w->hits = o;     o += ws_align((size_t)plan_blocks_max(Q, P) * 4);
+    // everything above sits at offsets that do not depend on max_tasks: a lookup done for one table size (encode_hash's epilogue)
+    // stays valid when the call is repeated with a larger table
     w->task = o;     o += ws_align((size_t)max_tasks * sizeof(int4));
     w->task_qr = o;  o += tiled ? ws_align((size_t)max_tasks * TILED_QB * 8) : 0;
-    w->pcell = o;    o += ws_align(qp);
     w->partial = o;  o += ws_align((size_t)max_tasks * (tiled ? TILED_QB : 8) * k * 8);
     w->qpad = o;     o += tiled ? ws_align((size_t)Q * ((d + 3) / 4) * 16) : 0;
     w->tauq = o;     o += ws_align((size_t)Q * 8);
@@ -1399,12 +1365,12 @@ static void launch_bscan2(const BArgs &a, int d4, unsigned grid, hipStream_t s) 
     else hipLaunchKernelGGL((bscan2_kernel<64, 4, METRIC, 2>), dim3(grid), dim3(256), 0, s, a);
 }
 
-int bucket_scan_run(const BucketScanCall &c) {
+// BArgs (what the scan kernels take) and PlanArgs (what the lookup takes) of one call: pointers into the caller's workspace.
+static int bucket_scan_args(const BucketScanCall &c, BArgs &a, PlanArgs &pa, int &metric_out, bool &prep_out) {
     BWs w;
     blayout(c.Q, c.P, c.k, c.max_tasks, c.nb, c.d, c.tiled != 0, &w);
     NLSH_REQUIRE(c.workspace_bytes >= w.total, NLSH_E_WORKSPACE, "scan_topk(bucket-major): workspace %zu < %zu", c.workspace_bytes, w.total);
     const int d4 = (c.d + 3) / 4;
-    BArgs a;
     a.corpus = c.corpus; a.row_stride = c.row_stride; a.d = c.d; a.gid = c.gid; a.uniq = c.uniq; a.offsets = c.offsets; a.nb = c.nb;
     // cells exist for the tiled schedule only (a window is one 256-row segment of its task shape); the wave-level schedule ignores them
     const bool cells = c.tiled && c.cell_of && c.cell_offsets && c.n_cells > 0;
@@ -1420,32 +1386,61 @@ int bucket_scan_run(const BucketScanCall &c) {
     if (c.tiled && !prep) { a.qpad = c.queries; a.qpad_stride = c.q_stride; }
     a.out_dist = c.out_dist; a.out_idx = c.out_idx; a.out_keys = c.out_keys; a.out_ncand = c.out_ncand; a.status = c.status;
     char *base = (char *)c.workspace;
-    a.pbkt = (int32_t *)(base + w.pbkt); a.prec = (int4 *)(base + w.prec); a.inv_q = (int32_t *)(base + w.inv_q);
-    a.bcount = (int32_t *)(base + w.bcount); a.pairoff = (int32_t *)(base + w.pairoff); a.taskoff = (int32_t *)(base + w.taskoff); a.bgroups = (int32_t *)(base + w.bgroups);
-    a.counters = (int32_t *)(base + w.counters); a.btot = (int32_t *)(base + w.btot); a.hits = (int32_t *)(base + w.hits); a.border = c.bucket_order; a.task = (int4 *)(base + w.task); a.task_qr = c.tiled ? (int2 *)(base + w.task_qr) : nullptr; a.pcell = (int32_t *)(base + w.pcell); a.partial = (uint64_t *)(base + w.partial);
+    a.ppair = (int4 *)(base + w.ppair); a.prec = (int4 *)(base + w.prec); a.inv_q = (int32_t *)(base + w.inv_q);
+    a.bcount = (int32_t *)(base + w.bcount); a.cellrec = (int4 *)(base + w.cellrec); a.lookback = (unsigned long long *)(base + w.lookback);
+    a.hits = (int32_t *)(base + w.hits); a.border = c.bucket_order; a.task = (int4 *)(base + w.task);
+    a.task_qr = c.tiled ? (int2 *)(base + w.task_qr) : nullptr; a.partial = (uint64_t *)(base + w.partial);
     a.max_tasks = c.max_tasks;
     a.tauq = (unsigned long long *)(base + w.tauq);
 
+    pa.uniq = a.uniq; pa.offsets = a.offsets; pa.cell_of = a.cell_of; pa.coffsets = a.coffsets; pa.nb = a.nb;
+    pa.stride = 1; pa.nco = a.nb;   // the launcher of the lookup sizes the coarse table for the LDS it has (plan_coarse)
+    pa.seg = a.seg; pa.P = a.P; pa.Q = a.Q; pa.qkeys = a.qkeys; pa.qnkeys = a.nkeys;
+    pa.bcount = a.bcount; pa.ppair = a.ppair; pa.hits = a.hits; pa.status = a.status; pa.tauq = a.tauq;
+    pa.lookback = a.lookback; pa.n_lookback = (a.nc + 255) / 256;
+    pa.queries = c.queries; pa.q_stride = c.q_stride; pa.qpad = a.qpad_w; pa.qpad_stride = (long long)d4 * 4; pa.d = c.d; pa.d4p = d4;
+    pa.prep_metric = prep ? metric : -1;
+    pa.enabled = 1;
+    metric_out = metric;
+    prep_out = prep;
+    return NLSH_OK;
+}
+
+int bucket_scan_plan_args(const BucketScanCall &c, PlanArgs *pa) {
+    BArgs a;
+    int metric;
+    bool prep;
+    return bucket_scan_args(c, a, *pa, metric, prep);
+}
+
+int bucket_scan_run(const BucketScanCall &c) {
+    BArgs a;
+    PlanArgs pa;
+    int metric;
+    bool prep;
+    const int rc = bucket_scan_args(c, a, pa, metric, prep);
+    if (rc != NLSH_OK) return rc;
+    const int d4 = (c.d + 3) / 4;
+
     hipStream_t s = c.stream;
+    const unsigned gp = (unsigned)((c.Q * c.P + 255) / 256);
     if (c.phases & NLSH_PHASE_PLAN) {
-        const unsigned gp = (unsigned)((c.Q * c.P + 255) / 256);
-        int stride = 1;
-        while ((long long)stride * 1024 < c.nb) stride <<= 1;  // coarse table of bplan: <= 1024 entries
-        // Four launches.  (One fused launch with grid barriers between the steps of this counting sort was built and
-        // measured in r02: 127 us with agent-scope fences -- each writes back / invalidates an XCD's L2 --, 63 us with
-        // device-coherent sc1 accesses instead, against 35 us for the separate launches: crossing XCDs inside a kernel
-        // costs as much as a kernel boundary on this part.)  The per-bucket pair counters need no clearing launch: the
-        // scatter step hands every count back, so they are zero again after every call (workspace contract, nlsh_hip.h).
+        // The lookup as a launch of its own (caller-supplied keys; keys made by encode_hash are looked up in ITS epilogue and the
+        // caller passes NLSH_PHASE_PLAN_REST instead).  (One fused launch with grid barriers between the steps of this counting
+        // sort was built and measured in r02: 127 us with agent-scope fences -- each writes back / invalidates an XCD's L2 --, 63 us
+        // with device-coherent sc1 accesses instead, against 35 us for the separate launches: crossing XCDs inside a kernel costs as
+        // much as a kernel boundary on this part.)  The per-cell pair counters need no clearing launch: bscan_kernel hands every
+        // count back, so they are zero again after every call (workspace contract, nlsh_hip.h).
+        plan_coarse(pa, 1024);
         const unsigned gprep = prep ? (unsigned)((c.Q + 3) / 4) : 0u;   // the query copy rides in the same launch
-        hipLaunchKernelGGL(bplan_kernel, dim3(gp + gprep), dim3(256), 0, s, a, stride, gp, prep ? metric : -1);
-        // (r03: bcount + bscan as ONE single-workgroup launch for indexes of <= 8192 buckets -- strided bucket map, counts and prefixes
-        // through 64 KB of LDS, all loads of a thread's 8 buckets issued together -- took 23 us against 16.4 us for the two launches
-        // below (33 us before the loads were batched): one CU writes 12 k task descriptors slower than 23 workgroups do.)
-        if (a.nc > 0) {
-            const unsigned gb = (unsigned)((a.nc + 255) / 256);
-            hipLaunchKernelGGL(bcount_kernel, dim3(gb), dim3(256), 0, s, a);
-            hipLaunchKernelGGL(bscan_kernel, dim3(gb), dim3(256), 0, s, a, (int)gp);
-        }
+        hipLaunchKernelGGL(bplan_kernel, dim3(gp + gprep), dim3(256), 0, s, pa, gp);
+    }
+    if (c.phases & (NLSH_PHASE_PLAN | NLSH_PHASE_PLAN_REST)) {
+        // (r03: bcount + bscan as ONE single-workgroup launch for indexes of <= 8192 buckets took 23 us against 16.4 us for the two
+        // launches of r02-r05: one CU writes 12 k task descriptors slower than 23 workgroups do.  r06: one launch of all the
+        // workgroups with a look-back over their totals, see bscan_kernel.)
+        const int plan_blocks = (c.phases & NLSH_PHASE_PLAN) ? (int)gp : c.plan_blocks;
+        if (a.nc > 0) hipLaunchKernelGGL(bscan_kernel, dim3((unsigned)((a.nc + 255) / 256)), dim3(256), 0, s, a, plan_blocks);
         hipLaunchKernelGGL(bscatter_kernel, dim3(gp), dim3(256), 0, s, a);
     }
     if ((c.phases & NLSH_PHASE_SCAN) && c.max_tasks > 0) {

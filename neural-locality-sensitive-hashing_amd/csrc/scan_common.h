@@ -353,8 +353,24 @@ struct BucketScanCall {
     const int32_t *cell_of;       // nlsh_build_cells outputs, or nullptr / 0: every bucket is its own cell
     const int32_t *cell_offsets;
     int n_cells;
+    int plan_blocks;              // NLSH_PHASE_PLAN_REST: workgroups of the encode_hash launch that did the lookup (entries of `hits`)
 };
+// internal phase bit (not part of the C ABI's phase mask): the PLAN phase WITHOUT the bucket lookup, which the batch's encode_hash
+// launch already did in its epilogue (scan_plan.h, encode_plan_fuse_lookup): bscan + bscatter only
+#define NLSH_PHASE_PLAN_REST 8
+struct PlanArgs;
 size_t bucket_scan_workspace(long long Q, int P, int k, long long max_tasks, long long n_buckets, int d);
 int bucket_scan_run(const BucketScanCall &c);
+int bucket_scan_plan_args(const BucketScanCall &c, PlanArgs *pa);   // the lookup's arguments for this call's workspace
+
+// nlsh_scan_topk_cells_phase after argument validation, with the internal phase bit allowed; `call_out` (nullable) receives the
+// bucket-major call descriptor instead of running it (step.hip builds the fused lookup's arguments from it)
+int scan_topk_cells_phase_checked(const float *corpus_sorted, int64_t row_stride, int d, const int32_t *gid, const int32_t *uniq_keys,
+                                  const int32_t *offsets, const int32_t *bucket_order, int32_t n_buckets, const int32_t *cell_of,
+                                  const int32_t *cell_offsets, int32_t n_cells, const float *inv_norm, const float *queries, int64_t q_stride,
+                                  int64_t Q, const int32_t *qkeys, const int32_t *nkeys, int P, int k, int metric, int algo, int seg_rows,
+                                  float *out_dist, int32_t *out_idx, uint64_t *out_keys, int32_t *out_ncand, int32_t *status, void *workspace,
+                                  size_t workspace_bytes, int64_t max_tasks, void *ev_scan_begin, void *ev_scan_end, nlsh_stream_t stream,
+                                  int phases, int plan_blocks, BucketScanCall *call_out);
 
 }  // namespace nlsh

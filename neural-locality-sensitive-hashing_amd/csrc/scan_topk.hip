@@ -294,6 +294,21 @@ extern "C" int nlsh_scan_topk_cells_phase(const float *corpus_sorted, int64_t ro
                               uint64_t *out_keys, int32_t *out_ncand, int32_t *status, void *workspace, size_t workspace_bytes,
                               int64_t max_tasks, void *ev_scan_begin, void *ev_scan_end, nlsh_stream_t stream, int phases) {
     NLSH_REQUIRE(phases >= 1 && phases <= (NLSH_PHASE_PLAN | NLSH_PHASE_SCAN | NLSH_PHASE_MERGE), NLSH_E_INVALID, "scan_topk: phases=%d", phases);
+    return nlsh::scan_topk_cells_phase_checked(corpus_sorted, row_stride, d, gid, uniq_keys, offsets, bucket_order, n_buckets, cell_of, cell_offsets, n_cells,
+                                               inv_norm, queries, q_stride, Q, qkeys, nkeys, P, k, metric, algo, seg_rows, out_dist, out_idx, out_keys,
+                                               out_ncand, status, workspace, workspace_bytes, max_tasks, ev_scan_begin, ev_scan_end, stream, phases, 0,
+                                               nullptr);
+}
+
+int nlsh::scan_topk_cells_phase_checked(const float *corpus_sorted, int64_t row_stride, int d, const int32_t *gid, const int32_t *uniq_keys,
+                                        const int32_t *offsets, const int32_t *bucket_order, int32_t n_buckets, const int32_t *cell_of,
+                                        const int32_t *cell_offsets, int32_t n_cells, const float *inv_norm, const float *queries,
+                                        int64_t q_stride, int64_t Q, const int32_t *qkeys, const int32_t *nkeys, int P, int k, int metric,
+                                        int algo, int seg_rows, float *out_dist, int32_t *out_idx, uint64_t *out_keys, int32_t *out_ncand,
+                                        int32_t *status, void *workspace, size_t workspace_bytes, int64_t max_tasks, void *ev_scan_begin,
+                                        void *ev_scan_end, nlsh_stream_t stream, int phases, int plan_blocks, BucketScanCall *call_out) {
+    NLSH_REQUIRE(phases >= 1 && phases <= 15 && !((phases & NLSH_PHASE_PLAN) && (phases & NLSH_PHASE_PLAN_REST)), NLSH_E_INVALID, "scan_topk: phases=%d", phases);
+    NLSH_REQUIRE(!(phases & NLSH_PHASE_PLAN_REST) || algo != NLSH_SCAN_QUERY_MAJOR, NLSH_E_INVALID, "scan_topk: the query-major schedule has no fused lookup");
     NLSH_REQUIRE(Q >= 0 && Q < (1ll << 31), NLSH_E_INVALID, "scan_topk: Q=%lld", (long long)Q);
     NLSH_REQUIRE(d >= 1 && d <= NLSH_MAX_DIM, NLSH_E_UNSUPPORTED, "scan_topk: d=%d not in [1,%d]", d, NLSH_MAX_DIM);
     NLSH_REQUIRE(k >= 1 && k <= NLSH_MAX_K, NLSH_E_UNSUPPORTED, "scan_topk: k=%d not in [1,%d]", k, NLSH_MAX_K);
@@ -322,9 +337,11 @@ extern "C" int nlsh_scan_topk_cells_phase(const float *corpus_sorted, int64_t ro
         BucketScanCall c = {corpus_sorted, row_stride, d, gid, uniq_keys, offsets, n_buckets, inv_norm, queries, q_stride, Q,
                             qkeys, nkeys, P, k, metric, seg_rows, out_dist, out_idx, out_keys, out_ncand, status, workspace,
                             workspace_bytes, max_tasks, ev_scan_begin, ev_scan_end, s, algo == NLSH_SCAN_BUCKET_TILED, bucket_order, phases,
-                            cell_of, cell_offsets, (int)n_cells};
+                            cell_of, cell_offsets, (int)n_cells, plan_blocks};
+        if (call_out) { *call_out = c; return NLSH_OK; }
         return bucket_scan_run(c);
     }
+    NLSH_REQUIRE(call_out == nullptr, NLSH_E_INVALID, "scan_topk: the query-major schedule has no call descriptor");
 
     if (metric == NLSH_METRIC_L2_EPS_FOLDED) metric = NLSH_METRIC_L2_EPS;   // the folded form exists in the tiled schedule only; the exact form is inside its tolerance
     ScanWs w;

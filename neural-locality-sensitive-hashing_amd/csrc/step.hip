@@ -9,9 +9,15 @@
 // the HIP runtime the kernels use; ADVICE r04: the facade used to dlopen "libamdhip64.so" by name for them); the streams and every
 // buffer stay the caller's.  Same kernels, same arguments, same results as the phase calls: only where the launches are issued from
 // changes.
+//
+// r06 (ABI v4): the batch is FIVE launches -- the bucket lookup of the PLAN phase runs in encode_hash's epilogue (scan_plan.h) whenever
+// the schedule is a bucket-major one, and the rest of the PLAN phase is two launches instead of three -- and the same batch exists
+// as a one-stream call for callers that do not pipeline (nlsh_query_batch: what `Indexer.query_tensors` issues).
 #include <new>
 
 #include "encode_common.h"
+#include "scan_common.h"
+#include "scan_plan.h"
 
 using namespace nlsh;
 
@@ -23,6 +29,35 @@ struct nlsh_step {
     bool done_pending;   // hold_done: the caller still has to release the batch (nlsh_step_release)
 };
 
+// One batch's scan call as the bucket-major descriptor (validated), or -- query-major schedule -- nothing (fused = false).
+static int scan_call(const nlsh_step_desc_t &d, const float *queries, int64_t q_stride, void *ev0, void *ev1, nlsh_stream_t stream, int phases,
+                     int plan_blocks, BucketScanCall *call_out) {
+    return scan_topk_cells_phase_checked(d.corpus_sorted, d.row_stride, d.d, d.gid, d.uniq_keys, d.offsets, d.bucket_order, d.n_buckets, d.cell_of,
+                                         d.cell_offsets, d.n_cells, d.inv_norm, queries, q_stride, d.Q, d.qkeys, d.nkeys, d.n_probes, d.k, d.metric,
+                                         d.algo, d.seg_rows, d.out_dist, d.out_idx, d.out_keys, d.out_ncand, d.status, d.workspace, d.workspace_bytes,
+                                         d.max_tasks, ev0, ev1, stream, phases, plan_blocks, call_out);
+}
+
+static bool fuses_lookup(const nlsh_step_desc_t &d) { return d.algo != NLSH_SCAN_QUERY_MAJOR && d.n_probes <= 64 && d.n_buckets > 0; }
+
+// encode_hash with the bucket lookup in its epilogue when the schedule allows it; *plan_phase = what is left of the PLAN phase
+static int launch_encode(EncPlan &enc, const nlsh_step_desc_t &d, const float *queries, int64_t q_stride, uint64_t seed, hipStream_t s, int *plan_phase,
+                         int *plan_blocks) {
+    *plan_phase = NLSH_PHASE_PLAN;
+    *plan_blocks = 0;
+    if (!fuses_lookup(d)) return encode_plan_launch(enc, queries, q_stride, seed, s);
+    BucketScanCall c;
+    int rc = scan_call(d, queries, q_stride, nullptr, nullptr, (nlsh_stream_t)s, NLSH_PHASE_PLAN_REST, 0, &c);
+    if (rc != NLSH_OK) return rc;
+    PlanArgs pa;
+    rc = bucket_scan_plan_args(c, &pa);
+    if (rc == NLSH_OK) rc = encode_plan_fuse_lookup(enc, pa);   // idempotent: the first call of a slot sizes the coarse table's LDS
+    if (rc != NLSH_OK) return rc;
+    *plan_phase = NLSH_PHASE_PLAN_REST;
+    *plan_blocks = (int)enc.grid;
+    return encode_plan_launch(enc, queries, q_stride, seed, s, &pa);
+}
+
 static int make_event(hipEvent_t *e) {
     NLSH_CHECK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     return NLSH_OK;
@@ -33,6 +68,9 @@ extern "C" int nlsh_step_create(const nlsh_step_desc_t *desc, size_t desc_bytes,
     NLSH_REQUIRE(desc_bytes == sizeof(nlsh_step_desc_t), NLSH_E_INVALID, "step_create: descriptor of %zu bytes, this library's is %zu (ABI %d)",
                  desc_bytes, sizeof(nlsh_step_desc_t), NLSH_ABI_VERSION);
     NLSH_REQUIRE(desc->front && desc->mid && desc->tail, NLSH_E_INVALID, "step_create: the front, mid and tail streams must be real streams (not the default stream)");
+    NLSH_REQUIRE(desc->front != desc->mid && desc->mid != desc->tail && desc->front != desc->tail && desc->plan != desc->front && desc->plan != desc->mid &&
+                     desc->plan != desc->tail,
+                 NLSH_E_INVALID, "step_create: front, plan, mid and tail must be DIFFERENT streams (the stages overlap only across streams, and an event is recorded on one and waited for on the next)");
     NLSH_REQUIRE(desc->n_layers >= 1 && desc->n_layers <= NLSH_MAX_LAYERS && desc->dims, NLSH_E_INVALID, "step_create: n_layers=%d", desc->n_layers);
     NLSH_REQUIRE(desc->n_probes >= 1 && desc->n_probes <= NLSH_MAX_PROBES, NLSH_E_UNSUPPORTED, "step_create: n_probes=%d not in [1,%d] (one scan call per batch)",
                  desc->n_probes, NLSH_MAX_PROBES);
@@ -47,6 +85,18 @@ extern "C" int nlsh_step_create(const nlsh_step_desc_t *desc, size_t desc_bytes,
     s->done_pending = false;
     int rc = encode_plan_fill(s->enc, desc->Q, desc->n_layers, s->dims, desc->packed, desc->act, desc->key_mode, desc->n_probes, desc->n_multi_rows, 0,
                               nullptr, nullptr, nullptr, desc->qkeys, desc->nkeys);
+    // the scan call's own argument checks (workspace alignment and size, strides, limits) run HERE, on a stand-in batch pointer, so
+    // that a bad descriptor fails before anything is enqueued (they used to fail inside the first enqueue, behind its encode)
+    if (rc == NLSH_OK) {
+        BucketScanCall c;
+        rc = scan_call(s->d, desc->corpus_sorted ? desc->corpus_sorted : (const float *)desc->workspace, desc->row_stride >= desc->d ? desc->row_stride : desc->d,
+                       nullptr, nullptr, desc->front, NLSH_PHASE_SCAN, 0, desc->algo != NLSH_SCAN_QUERY_MAJOR ? &c : nullptr);
+        if (rc == NLSH_OK && desc->algo != NLSH_SCAN_QUERY_MAJOR) {
+            PlanArgs pa;
+            rc = bucket_scan_plan_args(c, &pa);
+            if (rc == NLSH_OK && fuses_lookup(s->d)) rc = encode_plan_fuse_lookup(s->enc, pa);
+        }
+    }
     if (rc == NLSH_OK) rc = make_event(&s->ready);
     if (rc == NLSH_OK) rc = make_event(&s->encoded);
     if (rc == NLSH_OK) rc = make_event(&s->planned);
@@ -79,12 +129,8 @@ extern "C" int nlsh_step_set_weights(nlsh_step_t *s, const float *packed) {
     return NLSH_OK;
 }
 
-static int scan_phase(const nlsh_step *s, const float *queries, int64_t q_stride, void *ev0, void *ev1, nlsh_stream_t stream, int phases) {
-    const nlsh_step_desc_t &d = s->d;
-    return nlsh_scan_topk_cells_phase(d.corpus_sorted, d.row_stride, d.d, d.gid, d.uniq_keys, d.offsets, d.bucket_order, d.n_buckets, d.cell_of,
-                                      d.cell_offsets, d.n_cells, d.inv_norm, queries, q_stride, d.Q, d.qkeys, d.nkeys, d.n_probes, d.k, d.metric,
-                                      d.algo, d.seg_rows, d.out_dist, d.out_idx, d.out_keys, d.out_ncand, d.status, d.workspace, d.workspace_bytes,
-                                      d.max_tasks, ev0, ev1, stream, phases);
+static int scan_phase(const nlsh_step *s, const float *queries, int64_t q_stride, void *ev0, void *ev1, nlsh_stream_t stream, int phases, int plan_blocks) {
+    return scan_call(s->d, queries, q_stride, ev0, ev1, stream, phases, plan_blocks, nullptr);
 }
 
 extern "C" int nlsh_query_step_enqueue(nlsh_step_t *s, const float *queries, int64_t q_stride, uint64_t seed, nlsh_stream_t producer,
@@ -107,7 +153,8 @@ extern "C" int nlsh_query_step_enqueue(nlsh_step_t *s, const float *queries, int
         NLSH_CHECK_HIP(hipEventRecord(s->ready, (hipStream_t)producer));
         NLSH_CHECK_HIP(hipStreamWaitEvent(front, s->ready, 0));
     }
-    int rc = encode_plan_launch(s->enc, queries, q_stride, seed, front);
+    int plan_phase, plan_blocks;
+    int rc = launch_encode(s->enc, s->d, queries, q_stride, seed, front, &plan_phase, &plan_blocks);
     if (rc != NLSH_OK) return rc;
     hipStream_t hp = front;
     if (s->d.plan) {                                                  // four stages: the PLAN phase on a stream of its own behind the encode
@@ -115,15 +162,15 @@ extern "C" int nlsh_query_step_enqueue(nlsh_step_t *s, const float *queries, int
         NLSH_CHECK_HIP(hipEventRecord(s->encoded, front));
         NLSH_CHECK_HIP(hipStreamWaitEvent(hp, s->encoded, 0));
     }
-    rc = scan_phase(s, queries, q_stride, nullptr, nullptr, hp, NLSH_PHASE_PLAN);
+    rc = scan_phase(s, queries, q_stride, nullptr, nullptr, hp, plan_phase, plan_blocks);
     if (rc != NLSH_OK) return rc;
     NLSH_CHECK_HIP(hipEventRecord(s->planned, hp));
     NLSH_CHECK_HIP(hipStreamWaitEvent(mid, s->planned, 0));
-    rc = scan_phase(s, queries, q_stride, ev_scan_begin, ev_scan_end, mid, NLSH_PHASE_SCAN);
+    rc = scan_phase(s, queries, q_stride, ev_scan_begin, ev_scan_end, mid, NLSH_PHASE_SCAN, 0);
     if (rc != NLSH_OK) return rc;
     NLSH_CHECK_HIP(hipEventRecord(s->scanned, mid));
     NLSH_CHECK_HIP(hipStreamWaitEvent(tail, s->scanned, 0));
-    rc = scan_phase(s, queries, q_stride, nullptr, nullptr, tail, NLSH_PHASE_MERGE);
+    rc = scan_phase(s, queries, q_stride, nullptr, nullptr, tail, NLSH_PHASE_MERGE, 0);
     if (rc != NLSH_OK) return rc;
     if (s->d.hold_done) s->done_pending = true;                       // the caller queues more work on the tail stream (the shard exchange) first
     else NLSH_CHECK_HIP(hipEventRecord(s->done, tail));
@@ -148,4 +195,33 @@ extern "C" int nlsh_step_busy(nlsh_step_t *s) {
     }
     set_error("hipEventQuery failed: %s", hipGetErrorString(e));
     return NLSH_E_HIP;
+}
+
+// The same batch on ONE stream, nothing kept between calls (the streams and hold_done of `desc` are ignored): encode_hash with the
+// bucket lookup in its epilogue, then bscan, bscatter, the scan kernel and bmerge -- five launches.  `lookup_done` != 0 repeats the
+// scan part only, on keys (and their lookup) an earlier call of the same batch left in `qkeys` / the workspace: the retry after a
+// task-table overflow (status[1] = 1; the lookup's records sit at workspace offsets that do not depend on max_tasks), with the
+// lookup redone by the stand-alone kernel.
+extern "C" int nlsh_query_batch(const nlsh_step_desc_t *desc, size_t desc_bytes, const float *queries, int64_t q_stride, uint64_t seed, int64_t row0,
+                                int lookup_done, void *ev_scan_begin, void *ev_scan_end, nlsh_stream_t stream) {
+    NLSH_REQUIRE(desc, NLSH_E_INVALID, "query_batch: null pointer");
+    NLSH_REQUIRE(desc_bytes == sizeof(nlsh_step_desc_t), NLSH_E_INVALID, "query_batch: descriptor of %zu bytes, this library's is %zu (ABI %d)", desc_bytes,
+                 sizeof(nlsh_step_desc_t), NLSH_ABI_VERSION);
+    NLSH_REQUIRE(desc->Q >= 0, NLSH_E_INVALID, "query_batch: Q=%lld", (long long)desc->Q);
+    if (desc->Q == 0) return NLSH_OK;
+    NLSH_REQUIRE(queries, NLSH_E_INVALID, "query_batch: null pointer");
+    NLSH_REQUIRE(desc->n_layers >= 1 && desc->n_layers <= NLSH_MAX_LAYERS && desc->dims && desc->dims[0] == desc->d, NLSH_E_INVALID,
+                 "query_batch: n_layers=%d, encoder input vs corpus dimension %d", desc->n_layers, desc->d);
+    NLSH_REQUIRE(desc->n_probes >= 1 && desc->n_probes <= NLSH_MAX_PROBES, NLSH_E_UNSUPPORTED, "query_batch: n_probes=%d not in [1,%d] (one scan call per batch)",
+                 desc->n_probes, NLSH_MAX_PROBES);
+    hipStream_t s = (hipStream_t)stream;
+    int plan_phase = NLSH_PHASE_PLAN, plan_blocks = 0;
+    if (!lookup_done) {
+        EncPlan enc;
+        int rc = encode_plan_fill(enc, desc->Q, desc->n_layers, desc->dims, desc->packed, desc->act, desc->key_mode, desc->n_probes, desc->n_multi_rows, row0, nullptr,
+                                  nullptr, nullptr, desc->qkeys, desc->nkeys);
+        if (rc == NLSH_OK) rc = launch_encode(enc, *desc, queries, q_stride, seed, s, &plan_phase, &plan_blocks);
+        if (rc != NLSH_OK) return rc;
+    }
+    return scan_call(*desc, queries, q_stride, ev_scan_begin, ev_scan_end, stream, plan_phase | NLSH_PHASE_SCAN | NLSH_PHASE_MERGE, plan_blocks, nullptr);
 }

@@ -28,7 +28,7 @@ SYMBOLS = (
     "nlsh_build_csr_workspace", "nlsh_build_csr", "nlsh_bucket_order_workspace", "nlsh_bucket_order", "nlsh_build_cells_workspace", "nlsh_build_cells", "nlsh_gather_rows",
     "nlsh_scan_workspace", "nlsh_scan_workspace_layout", "nlsh_scan_topk", "nlsh_scan_topk_phase", "nlsh_scan_topk_cells_phase",
     "nlsh_merge_topk",
-    "nlsh_step_create", "nlsh_step_destroy", "nlsh_step_set_weights", "nlsh_query_step_enqueue", "nlsh_step_release", "nlsh_step_busy",
+    "nlsh_step_create", "nlsh_step_destroy", "nlsh_step_set_weights", "nlsh_query_step_enqueue", "nlsh_step_release", "nlsh_step_busy", "nlsh_query_batch",
 )
 
 
@@ -125,6 +125,8 @@ def lib():
     L.nlsh_step_set_weights.argtypes = [vp, vp]
     L.nlsh_query_step_enqueue.restype = i32
     L.nlsh_query_step_enqueue.argtypes = [vp, vp, i64, u64, vp, vp, vp]
+    L.nlsh_query_batch.restype = i32
+    L.nlsh_query_batch.argtypes = [ctypes.POINTER(StepDesc), sz, vp, i64, u64, i64, i32, vp, vp, vp]
     _lib = L
     return L
 

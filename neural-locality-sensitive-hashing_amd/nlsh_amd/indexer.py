@@ -12,6 +12,7 @@ reference quirks: int16 key wrap (F2), single-probe trailing partial batch (F6),
 last key's bucket rows (F7).  No CPU fallback exists anywhere in this module.
 """
 import gc
+import threading
 from typing import Dict, List, Optional, Sequence, Set, Tuple
 
 import numpy as np
@@ -22,6 +23,49 @@ from .data import metric_of
 from .hashings import host_key_set, keys_to_sets
 
 HASH_BATCH = 4096  # nlsh/indexer.py:40 default batch_size
+
+
+class _CollectorPause:
+    """The cyclic collector paused for a region, re-entrant and shared by every thread of the process (the collector's switch is one
+    process-wide flag, so the pause has to be one process-wide object): the FIRST region to open records the state the application
+    left the collector in and disables it, regions opened meanwhile -- nested in the same thread (`query` -> `_plain_lists`) or by
+    `query()` calls of other threads -- only count, and the LAST one to close restores what the first one found.  A caller that had
+    the collector disabled gets it back disabled; a caller that enables it while a region is open keeps it enabled (the exit only
+    ever ENABLES, and only when the pause itself disabled).  What the gc module cannot show is another thread calling
+    `gc.disable()` while a region is open (a no-op on an already disabled collector): that thread finds the collector enabled again
+    once the last region closes -- INTEGRATION.md says so.
+
+    `application_state()` is the collector state the application chose: what the first open region found, `gc.isenabled()` when none
+    is open.  `Indexer.promote_results` asks it (inside a paused `query()` `gc.isenabled()` is always False)."""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._depth = 0
+        self._found_enabled = False
+
+    def __enter__(self):
+        with self._lock:
+            if self._depth == 0:
+                self._found_enabled = gc.isenabled()
+                if self._found_enabled:
+                    gc.disable()
+            self._depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        with self._lock:
+            self._depth -= 1
+            if self._depth == 0 and self._found_enabled:
+                self._found_enabled = False
+                gc.enable()
+        return False
+
+    def application_state(self):
+        with self._lock:
+            return self._found_enabled if self._depth else gc.isenabled()
+
+
+_collector_pause = _CollectorPause()
 
 
 def _load_fastlists():
@@ -472,8 +516,93 @@ class Indexer:
     def query_tensors(self, query_vectors, k=10, hash_times=10, seed=None, want_keys=False, check=True, events=None):
         """Device-resident form of `query`: hashing + scan, nothing copied to the host.
         events = (begin, end) torch.cuda.Event pair (already recorded once) bracketing the scan kernel."""
-        keys, nkeys = self.hash_device(query_vectors, hash_times=hash_times, seed=seed)
-        return self.scan_tensors(query_vectors, keys, nkeys, k=k, want_keys=want_keys, check=check, events=events)
+        return self._batch_tensors(query_vectors, k, hash_times, seed, want_keys=want_keys, check=check, events=events)[:4]
+
+    def _fuses(self, q, hash_times, algo):
+        """One `nlsh_query_batch` call (ABI v4: five launches, the bucket lookup in the encode's epilogue) serves a batch when the
+        fused kernel may hash it at all (not a BatchNorm encoder in train mode), the key table fits one scan call and the schedule
+        is a bucket-major one (the query-major stream's PLAN phase is a single kernel of its own)."""
+        needs_train = getattr(self._hashing, "_needs_train_forward", None)
+        return (self.metric in ("l2", "cosine") and 1 <= hash_times <= _capi.MAX_PROBES and algo != _capi.SCAN_QUERY_MAJOR
+                and self.n_buckets > 0 and q.shape[0] > 0 and not (needs_train is not None and needs_train())
+                and hasattr(self._hashing, "encode_args"))
+
+    def _batch_tensors(self, query_vectors, k, hash_times, seed, want_keys=False, check=True, events=None, algo=None, row0=0,
+                       n_multi=None, out=None):
+        """hash + scan of one batch (or one row range of a batch: `row0`, `n_multi` = rows of the RANGE that are multi-probe, `out` =
+        the range's slice of the batch's key table) -> (dist, idx, ncand, keys64 | None, keys, nkeys).  One C-ABI call where the
+        fused form applies (`_fuses`), `hash_device` + `scan_tensors` otherwise; same results either way, bit for bit."""
+        if hash_times < 1:
+            raise ValueError(f"`n` should be positive integer, but got {hash_times}")
+        q = self._as_queries(query_vectors)
+        Q, d = q.shape
+        if algo is None:
+            algo = self.choose_algo(Q, hash_times)
+        if n_multi is None:
+            n_multi = self._n_multi_rows(Q)
+        if not self._fuses(q, hash_times, algo):
+            if row0 or out is not None:
+                keys, nkeys = self._hashing.hash_device(q, n=hash_times, n_multi_rows=n_multi, seed=seed, row0=row0, out=out)
+            else:
+                keys, nkeys = self.hash_device(q, hash_times=hash_times, seed=seed)
+            return self.scan_tensors(q, keys, nkeys, k=k, want_keys=want_keys, check=check, events=events, algo=algo) + (keys, nkeys)
+        if d != self.dim:
+            raise ValueError(f"query dim {d} != corpus dim {self.dim}")
+        import ctypes
+        L, h, dev, P = _capi.lib(), self._hashing, q.device, hash_times
+        if out is not None:
+            keys, nkeys = out
+        else:
+            keys = torch.empty((Q, P), dtype=torch.int32, device=dev)
+            nkeys = torch.empty((Q,), dtype=torch.int32, device=dev)
+        out_dist = torch.empty((Q, k), dtype=torch.float32, device=dev)
+        pack = torch.empty((Q * k + Q + 2,), dtype=torch.int32, device=dev)    # ids, counts, status: ONE buffer, one copy for `query()`
+        out_idx, ncand, status = pack[:Q * k].view(Q, k), pack[Q * k:Q * k + Q], pack[Q * k + Q:]
+        out_keys = torch.empty((Q, k), dtype=torch.int64, device=dev) if want_keys else None
+        window = self.choose_window(Q, P, algo)
+        tkey = self._tkey(algo, Q, P)
+        if tkey not in self._max_tasks:
+            grown = [v for (a_, q_, p_, w_), v in self._max_tasks.items() if a_ == algo and q_ >= Q and p_ >= P and w_ == window]
+            self._max_tasks[tkey] = min(grown) if grown else self._estimate_tasks(Q, P, self.seg_rows or 512, algo)
+        if seed is None:
+            seed = h.next_seed()
+        (n_layers, dims_arr, packed_ptr, act, key_mode, n_probes), _ = h.encode_args(P, keys, nkeys)
+        stream = _stream(dev)
+        lookup_done = 0
+        while True:
+            max_tasks = self._max_tasks[tkey]
+            ws_bytes = L.nlsh_scan_workspace(Q, P, k, max_tasks, self.n_buckets, d)
+            wkey = (stream, True)
+            ws = self._ws.get(wkey)
+            if ws is None or ws.numel() < ws_bytes or ws.device != dev:
+                ws = self._ws[wkey] = torch.zeros((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
+            pre, post = self._scan_args(Q, d, keys, nkeys, k, algo, max_tasks, out_dist, out_idx, out_keys, ncand, status, ws, window)
+            (corpus, row_stride, d_, gid, uniq, offsets, order, n_buckets, cell_of, cell_offsets, n_cells, inv_norm) = pre
+            (Q_, qkeys_p, nkeys_p, P_, k_, metric, algo_, seg, od, oi, ok, nc, st, wsp, wsb, mt) = post
+            desc = _capi.StepDesc(
+                n_layers=n_layers, act=act, key_mode=key_mode, n_probes=n_probes, dims=ctypes.cast(dims_arr, ctypes.c_void_p), packed=packed_ptr,
+                n_multi_rows=int(n_multi), corpus_sorted=corpus, row_stride=row_stride, gid=gid, uniq_keys=uniq, offsets=offsets,
+                bucket_order=order, cell_of=cell_of, cell_offsets=cell_offsets, inv_norm=inv_norm, d=d_, n_buckets=n_buckets, n_cells=n_cells,
+                k=k_, metric=metric, algo=algo_, seg_rows=seg, hold_done=0, Q=Q_, qkeys=qkeys_p, nkeys=nkeys_p, out_dist=od, out_idx=oi,
+                out_keys=ok, out_ncand=nc, status=st, workspace=wsp, workspace_bytes=wsb, max_tasks=mt, front=None, plan=None, mid=None, tail=None)
+            try:
+                _capi.check(L.nlsh_query_batch(ctypes.byref(desc), ctypes.sizeof(desc), q.data_ptr(), q.stride(0), seed, int(row0), lookup_done,
+                                               events[0].cuda_event if events else None, events[1].cuda_event if events else None, stream))
+            except _capi.NlshHipError:
+                self._ws.pop(wkey, None)    # a call that failed part-way may have left the counters at the head non-zero
+                raise
+            if not check:
+                break
+            needed, overflow = status.cpu().tolist()
+            if not overflow:
+                self._trim_task_table(tkey, needed, max_tasks)
+                break
+            self._grow_task_table(tkey, needed, overflow)           # task table too small: grow and repeat the scan part on the same keys
+            lookup_done = 1
+        self.last_status = status
+        self.last_algo, self.last_window = algo, window
+        self._last_pack, self._last_tkey, self._last_max_tasks = pack, tkey, max_tasks
+        return out_dist, out_idx, ncand, out_keys, keys, nkeys
 
     def _rows_of_key(self, key):
         """Ascending global row ids of one bucket (host list) or [] for an unknown key.  Called once per query with fewer than k
@@ -492,14 +621,26 @@ class Indexer:
             self._perm_host = self.gid.cpu().numpy().astype(np.int64)
         return self._perm_host[span[0]:span[1]].tolist()
 
-    def _host_results(self, q, keys, nkeys, k):
+    def _range_tensors(self, q, keys, nkeys, k, lo, hi, algo, fused):
+        """One row range of a `query()` batch on the stream: `fused` = (hash_times, seed, rows of the batch that are multi-probe) --
+        the range is hashed AND scanned by one `nlsh_query_batch` call into its slice of the batch's key table; None: the table was
+        filled by a whole-batch `hash_device` and the range is only scanned."""
+        if fused is None:
+            self.scan_tensors(q[lo:hi], keys[lo:hi], nkeys[lo:hi], k=k, check=False, algo=algo)
+        else:
+            hash_times, seed, n_multi = fused
+            self._batch_tensors(q[lo:hi], k, hash_times, seed, check=False, algo=algo, row0=lo, n_multi=min(max(n_multi - lo, 0), hi - lo),
+                                out=(keys[lo:hi], nkeys[lo:hi]))
+
+    def _host_results(self, q, keys, nkeys, k, fused=None):
         """Scan + device->host copies of (ids, candidate counts, status) and of the key table into pinned buffers + ONE
         stream synchronisation: the only sync of a `query()` call (the key table rides along because the F7 rule needs
         the key sets of the few queries with < k candidates: 400 KB more on the wire is cheaper than a second round of
         device indexing + copies + syncs after the first).  Repeats the scan if the task table overflowed."""
         Q, P = keys.shape
+        algo = self.choose_algo(Q, P)
         while True:
-            _, idx, ncand, _ = self.scan_tensors(q, keys, nkeys, k=k, check=False)
+            self._range_tensors(q, keys, nkeys, k, 0, Q, algo, fused)
             pack, tkey = self._last_pack, self._last_tkey
             n, nk = pack.numel(), Q * P + Q
             pin = self._pin
@@ -533,7 +674,7 @@ class Indexer:
             return int(self.query_chunks)
         return 1 if self.defer_result_release else 2
 
-    def _chunked_results(self, q, keys, nkeys, k, n_chunks):
+    def _chunked_results(self, q, keys, nkeys, k, n_chunks, fused=None):
         """Generator over row ranges of the batch: (lo, hi, ids [hi-lo, k], counts [hi-lo], keys, nkeys) as host arrays, each
         yielded as soon as ITS scan and copies are done (one event per range; later ranges keep the device busy meanwhile)."""
         Q, P = keys.shape
@@ -549,7 +690,7 @@ class Indexer:
         inflight = []
 
         def launch(c, lo, hi):
-            self.scan_tensors(q[lo:hi], keys[lo:hi], nkeys[lo:hi], k=k, check=False, algo=algo)
+            self._range_tensors(q, keys, nkeys, k, lo, hi, algo, fused)
             pack, tkey = self._last_pack, self._last_tkey
             base, n, m = c * words, pack.numel(), hi - lo
             pin[base:base + n].copy_(pack, non_blocking=True)
@@ -611,12 +752,11 @@ class Indexer:
     @classmethod
     def _plain_lists(cls, idx_h, nc_h):
         """Host arrays -> (list of id rows, list of counts): one C-level conversion each for the whole batch."""
-        was_enabled = gc.isenabled()
-        promote = was_enabled and cls.promote_results and len(nc_h) >= 512 and gc.get_freeze_count() == 0
+        # the state the APPLICATION left the collector in -- not `gc.isenabled()`, which is False whenever `query()` holds its pause
+        promote = _collector_pause.application_state() and cls.promote_results and len(nc_h) >= 512 and gc.get_freeze_count() == 0
         if promote:
             gc.collect(0)
-        gc.disable()        # 10^4 fresh lists would trigger a dozen collections over the whole heap: a third of the conversion
-        try:
+        with _collector_pause:   # 10^4 fresh lists would trigger a dozen collections over the whole heap: a third of the conversion
             if _rows_to_lists is not None and idx_h.dtype == np.int32 and idx_h.ndim == 2 and idx_h.flags.c_contiguous:
                 out = _rows_to_lists(idx_h, idx_h.shape[0], idx_h.shape[1], bool(cls.untracked_results)), nc_h.tolist()
             else:
@@ -628,9 +768,6 @@ class Indexer:
                 if Indexer._promotions % cls._FULL_COLLECT_EVERY == 0:
                     gc.collect()
             return out
-        finally:
-            if was_enabled:
-                gc.enable()
 
     def _to_lists(self, key_sets, idx_h, nc_h, k):
         """Host arrays -> the reference's (List[List[int]], List[int]) (indexer.py:88-95)."""
@@ -668,31 +805,41 @@ class Indexer:
     # from paying.  Paused across the call the fresh lists are walked once, after the call, whatever the split.  No generation is
     # rewritten and nothing is frozen (unlike `promote_results`): the collector simply does not run inside the call, as it already did
     # not inside the conversions.  False restores r04's behaviour (tools/query_modes.py times both).
+    # The pause is `_collector_pause`: one re-entrant, lock-protected region counter for the whole process, so concurrent `query()` calls
+    # of two threads and the nested pause of `_plain_lists` leave the collector as the FIRST of them found it (r06).
     pause_collector_for_call = True
 
     def query(self, query_vectors, k=10, hash_times=10, seed=None) -> Tuple[List[List[int]], List[int]]:
         """nlsh/indexer.py:56-96.  `seed` (not in the reference): the Philox seed of the multi-probe draws; None takes the next one
         from the hasher's call counter, like every other hashing call."""
-        if not (self.pause_collector_for_call and gc.isenabled()):
+        if not self.pause_collector_for_call:
             return self._keep(self._query(query_vectors, k, hash_times, seed))
-        gc.disable()
-        try:
+        with _collector_pause:
             return self._keep(self._query(query_vectors, k, hash_times, seed))
-        finally:
-            gc.enable()
 
     def _query(self, query_vectors, k, hash_times, seed):
         if self.metric not in ("l2", "cosine"):
             return self._query_generic(query_vectors, k, hash_times)
         q = self._as_queries(query_vectors)
-        keys, nkeys = self.hash_device(q, hash_times=hash_times, seed=seed)
+        Q = q.shape[0]
+        if hash_times < 1:
+            raise ValueError(f"`n` should be positive integer, but got {hash_times}")
+        fused = None
+        if self._fuses(q, hash_times, self.choose_algo(Q, hash_times)):
+            # every row range is hashed and scanned by ONE call (five launches); the ranges share the batch's key table, seed and the
+            # Philox counters of its rows, so the split changes no key
+            keys = torch.empty((Q, hash_times), dtype=torch.int32, device=q.device)
+            nkeys = torch.empty((Q,), dtype=torch.int32, device=q.device)
+            fused = (hash_times, self._hashing.next_seed() if seed is None else seed, self._n_multi_rows(Q))
+        else:
+            keys, nkeys = self.hash_device(q, hash_times=hash_times, seed=seed)
         if keys.shape[1] > _capi.MAX_PROBES:
             _, idx, ncand, _ = self.scan_tensors(q, keys, nkeys, k=k)
             idx_h, nc_h = idx.cpu().numpy(), ncand.cpu().numpy()
             keys_h, nkeys_h = (keys.cpu().numpy(), nkeys.cpu().numpy()) if self.compat else (None, None)
         elif self._n_chunks() > 1 and q.shape[0] >= self._n_chunks() * self._CHUNK_MIN_ROWS:
             results, counts = [], []
-            for lo, hi, idx_h, nc_h, keys_h, nkeys_h in self._chunked_results(q, keys, nkeys, k, self._n_chunks()):
+            for lo, hi, idx_h, nc_h, keys_h, nkeys_h in self._chunked_results(q, keys, nkeys, k, self._n_chunks(), fused):
                 key_sets = {}
                 if self.compat:
                     for qi in np.nonzero(nc_h < k)[0].tolist():
@@ -702,7 +849,7 @@ class Indexer:
                 counts += c
             return results, counts
         else:
-            idx_h, nc_h, keys_h, nkeys_h = self._host_results(q, keys, nkeys, k)
+            idx_h, nc_h, keys_h, nkeys_h = self._host_results(q, keys, nkeys, k, fused)
         key_sets = {}
         if self.compat:  # F7 needs the key SET (Python iteration order) of the queries with < k candidates only
             for qi in np.nonzero(nc_h < k)[0].tolist():

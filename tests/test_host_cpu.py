@@ -22,7 +22,7 @@ def test_capi_library_exports_every_declared_symbol():
     lib = _capi.lib()
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} not exported"
-    assert lib.nlsh_abi_version() == 3
+    assert lib.nlsh_abi_version() == 4
     # pure host-side argument validation (no device needed): errors come back as codes + message
     dims = _capi.int_array([128, 256, 256, 16])
     # the 32x32x2 fragments of every layer + biases, then (r04) the hidden layers once more packed for 16x16x4 tiles (the 16-row form)
@@ -349,6 +349,92 @@ def test_query_pauses_the_collector_for_the_call_and_leaves_it_as_it_found_it(mo
     monkeypatch.setattr(Indexer, "pause_collector_for_call", False)
     ix.query("x")
     assert seen[-1] is True and gc.isenabled()
+
+
+def test_collector_pause_is_reentrant_and_shared_between_threads(monkeypatch):
+    """r06: two threads inside `query()` at once, and the pause `_plain_lists` nests inside it, leave the collector
+    as the FIRST region found it -- the thread that finishes first must not switch the collector back on under the other one, a caller
+    that had it disabled gets it back disabled, and one that enables it during a call keeps it enabled."""
+    import gc
+    import threading
+    from nlsh_amd import indexer
+    from nlsh_amd.indexer import Indexer
+    pause = indexer._collector_pause
+    ix = Indexer.__new__(Indexer)
+    a_inside, a_may_leave, b_done = threading.Event(), threading.Event(), threading.Event()
+    seen = {}
+
+    def fake_query(self, q, k, hash_times, seed):
+        if q == "a":                                    # thread A: enters first, leaves last
+            a_inside.set()
+            assert a_may_leave.wait(10)
+            seen["a_after_b_left"] = gc.isenabled()
+        else:                                           # thread B: enters while A is inside, leaves before it
+            seen["b_inside"] = gc.isenabled()
+            seen["b_app_state"] = pause.application_state()
+            with pause:                                 # what `_plain_lists` does inside a paused call
+                pass
+            seen["b_after_nested"] = gc.isenabled()
+        return [[1]], [1]
+    monkeypatch.setattr(Indexer, "_query", fake_query)
+    assert gc.isenabled() and pause._depth == 0
+    ta = threading.Thread(target=lambda: ix.query("a"))
+    ta.start()
+    assert a_inside.wait(10)
+
+    def run_b():
+        ix.query("b")
+        seen["after_b_returned"] = gc.isenabled()       # A is still inside: the collector must still be paused
+        b_done.set()
+    tb = threading.Thread(target=run_b)
+    tb.start()
+    assert b_done.wait(10)
+    a_may_leave.set()
+    ta.join(10)
+    tb.join(10)
+    assert seen == {"b_inside": False, "b_app_state": True, "b_after_nested": False, "after_b_returned": False, "a_after_b_left": False}
+    assert gc.isenabled() and pause._depth == 0         # the last region to close restored what the first one found
+    # an application that runs with the collector off gets it back off, whatever happened in between
+    gc.disable()
+    try:
+        with pause:
+            with pause:
+                assert pause.application_state() is False
+        assert not gc.isenabled()
+    finally:
+        gc.enable()
+    # a caller that switches the collector ON during a call keeps it on; the exit never disables
+    with pause:
+        gc.enable()
+    assert gc.isenabled()
+
+
+def test_promote_results_still_promotes_through_a_paused_query(monkeypatch):
+    """with `pause_collector_for_call` on (the default) `gc.isenabled()` is False inside `query()`, and
+    `_plain_lists` took that for "the application runs without a collector" -- `Indexer.promote_results = True` was a silent no-op on
+    the `query()` path.  It now asks the pause for the state the APPLICATION left: the promotion (freeze + unfreeze: the fresh lists
+    are in the oldest generation, the young counters at zero) happens through `query()` too, and not when the caller runs gc-off."""
+    import gc
+    import numpy as np
+    from nlsh_amd.indexer import Indexer
+    ix = Indexer.__new__(Indexer)
+    idx, nc = np.arange(10240, dtype=np.int32).reshape(1024, 10), np.full((1024,), 12, dtype=np.int32)
+    monkeypatch.setattr(Indexer, "_query", lambda self, q, k, hash_times, seed: Indexer._plain_lists(idx, nc))
+    monkeypatch.setattr(Indexer, "promote_results", True)
+    gc.collect()
+    before = Indexer._promotions
+    lists, counts = ix.query("x")
+    assert Indexer._promotions == before + 1 and lists == idx.tolist() and gc.isenabled()
+    assert gc.get_count()[0] < 64                       # the young generation does not hold the 1024 fresh lists any more
+    gc.disable()
+    try:
+        ix.query("x")
+        assert Indexer._promotions == before + 1 and not gc.isenabled()   # the application's own choice: nothing is promoted
+    finally:
+        gc.enable()
+    monkeypatch.setattr(Indexer, "pause_collector_for_call", False)
+    ix.query("x")
+    assert Indexer._promotions == before + 2
 
 
 def test_fastlists_builds_the_same_lists_as_ndarray_tolist():
