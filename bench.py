@@ -122,6 +122,7 @@ def parse(argv=None):
                          "(probed first, agreed by all ranks); allgather: all-gather + local selection (the fallback, selectable so that a first "
                          "contact with a fabric that refuses uneven all-to-all does not cost the run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-workloads", action="store_true", help="skip the `workloads` object (configs[2] and SURVEY 8(d)'s generator, 3 + 20 device-resident steps each) of the default run")
     ap.add_argument("--random-init", action="store_true", help="ignore the learned-hash checkpoint")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of each baseline sample")
     ap.add_argument("--rehearse-launch", action="store_true",
@@ -171,6 +172,130 @@ def collective_facts(world, dev, gpus):
         print(f"[bench] the {backend} all-reduce saw {facts['world_size_seen']} ranks, --gpus says {gpus}: refusing to print a line", file=sys.stderr)
         sys.exit(2)
     return facts
+
+
+def traffic_entry(key, shape, learned):
+    """(traffic bytes per launch, VALU wave-instructions per launch, clock held, source note) of the committed rocprofv3 --pmc pass
+    whose workload shape, schedule, row window AND kernel source hash equal this run's; Nones otherwise (a kernel change without a
+    new PMC pass nulls them instead of quoting stale counters)."""
+    try:
+        tr = json.load(open(TRAFFIC_FILE))
+        ent = tr["entries"].get(key)
+        if ent is not None and learned and tr.get("kernel_source_sha256") == kernel_source_hash():
+            w = ent["workload"]
+            if (w["N"], w["d"], w["Q"], w["H"], w["hash_times"], w["algo"], w["window_rows"]) == tuple(shape):
+                src = "profiles/" + os.path.basename(TRAFFIC_FILE) + " (rocprofv3 --pmc on the profile box, same workload, schedule and kernel sources; not this run)"
+                return ent["traffic_bytes_per_launch"], ent.get("valu_wave_instructions_per_launch"), ent.get("clock_held_GHz"), src, ent.get("dram_bytes_per_launch")
+    except (OSError, KeyError, ValueError, TypeError):
+        pass
+    return None, None, None, None, None
+
+
+def batch_sums(indexer, q, k, P, seed):
+    """(sum of the batch's candidate counts, rows of the buckets the batch probes at all -- each counted ONCE: what a schedule that shares
+    a fetched row between the queries probing its bucket has to read at least) of one batch, by an untimed recomputation."""
+    dev = q.device
+    sum_c = int(indexer.query_tensors(q, k=k, hash_times=P, seed=seed)[2].long().sum().item())
+    uniq_rows = None
+    if indexer.n_buckets:
+        bucket_rows = (indexer.offsets[1:] - indexer.offsets[:-1]).long()
+        kk, nn = indexer.hash_device(q, hash_times=P, seed=seed)
+        pos = torch.searchsorted(indexer.uniq_keys, kk.clamp(min=int(indexer.uniq_keys[0]), max=int(indexer.uniq_keys[-1]))).clamp(max=indexer.n_buckets - 1)
+        hit = (indexer.uniq_keys[pos] == kk) & (torch.arange(kk.shape[1], device=dev)[None, :] < nn[:, None])
+        uniq_rows = int(bucket_rows[torch.unique(pos[hit])].sum().item())
+    return sum_c, uniq_rows
+
+
+def bucket_major_roofline(kernel, metric, d, sum_c, uniq_rows, t_scan):
+    """The two roofs of a bucket-major schedule, both on algorithmic quantities measured live: pair flops against the fp32
+    vector peak, bytes of the batch's DISTINCT candidate rows against the HBM peak; bound = "valu" unless the HBM fraction is more
+    than 1.5x the VALU fraction."""
+    algo_flops = (3.0 * d if metric == "l2" else 2.0 * d) * sum_c      # (q-c), +eps, fma per element | one fma
+    unique_bytes = 4.0 * d * uniq_rows
+    valu_frac = algo_flops / t_scan / 1e12 / VALU_F32_PEAK_TFLOPS
+    hbm_frac = unique_bytes / t_scan / 1e9 / HBM_PEAK_GBPS
+    if 1.5 * valu_frac >= hbm_frac:
+        roof = {"bound": "valu", "kernel": kernel, "achieved": algo_flops / t_scan / 1e12, "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": valu_frac}
+    else:
+        roof = {"bound": "hbm", "kernel": kernel, "achieved": unique_bytes / t_scan / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_frac}
+    roof.update({"valu_frac": valu_frac, "hbm_frac_of_distinct_candidate_rows": hbm_frac, "distinct_candidate_row_bytes_per_launch": unique_bytes})
+    return roof
+
+
+SIDE_WORKLOADS = {
+    "glove": dict(workload="glove", data="manifold", N=1_183_514, d=100, H=24, metric="cosine", ckpt="glove_manifold_h24.npz",
+                  cfg="configs[2]: GloVe-1.2M-shaped (synth.glove_manifold, cosine, 24-bit full-width keys)"),
+    "clusters": dict(workload="sift1m", data="clusters", N=1_000_000, d=128, H=16, metric="l2", ckpt="sift1m_clusters_h16.npz",
+                     cfg="configs[1] on SURVEY 8(d)'s generator (synth.sift_like: 1,000 isotropic Gaussian clusters, sigma 24, standardised)"),
+}
+
+
+def side_workload(tag, args, dev, steps=20, warmup=3):
+    """One of the non-headline workloads inside the DEFAULT run: the code paths of `--workload glove` /
+    `--data clusters` -- learned hash from checkpoints/, `Indexer.query_tensors` steps back to back on one stream, the scan kernel
+    bracketed by HIP events on its launch stream -- 3 warm-up + 20 timed steps, no protocol region and no CPU leg.  The QPS protocol
+    is the reference's (nlsh/trainers/base.py:93-108) with the results left in HBM."""
+    from nlsh_amd import _capi, synth
+    from nlsh_amd.data import Glove, SIFT, brute_force_topk
+    from nlsh_amd.encoders import MultiLayerRelu
+    from nlsh_amd.hashings import MultivariateBernoulli
+    from nlsh_amd.indexer import Indexer
+    from nlsh_amd.metrics import calculate_recall
+    w = SIDE_WORKLOADS[tag]
+    N, d, H, metric, Q, k, P, B = w["N"], w["d"], w["H"], w["metric"], args.q, args.k, args.hash_times, 4
+    if w["workload"] == "glove":
+        corpus_h = synth.glove_manifold(N, d, seed=synth.SEED_DATA)
+        batches_h = [synth.glove_manifold(Q, d, seed=synth.SEED_QUERY + 17 * i) for i in range(B)]
+    else:
+        corpus_h, mean, std = synth.standardise(synth.sift_like(N, d, seed=synth.SEED_DATA))
+        batches_h = [synth.standardise(synth.sift_like(Q, d, seed=synth.SEED_QUERY + 17 * i), mean, std)[0] for i in range(B)]
+    arrs = np.load(os.path.join(ROOT, "neural-locality-sensitive-hashing_amd", "checkpoints", w["ckpt"]))
+    Ws, bs = [arrs[f"W{i}"] for i in range(3)], [arrs[f"b{i}"] for i in range(3)]
+    hashing = MultivariateBernoulli(MultiLayerRelu(d, [256, 256], with_bias=True), H, None, compat=H <= 16)
+    lin = [m for m in hashing._hasher.modules() if isinstance(m, torch.nn.Linear)]
+    with torch.no_grad():
+        for m, W, b in zip(lin, Ws, bs):
+            m.weight.copy_(torch.from_numpy(np.asarray(W, dtype=np.float32)))
+            m.bias.copy_(torch.from_numpy(np.asarray(b, dtype=np.float32)))
+    hashing.train_mode(False)
+    corpus = torch.from_numpy(corpus_h).to(dev)
+    qb = [torch.from_numpy(b).to(dev) for b in batches_h]
+    indexer = Indexer(hashing, corpus, SIFT.distance if metric == "l2" else Glove.distance, compat=H <= 16)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in ev:
+        a.record(); b.record()
+    indexer.query_tensors(qb[0], k=k, hash_times=P, seed=999)           # sizes the task table (checked call), untimed
+    for i in range(warmup):
+        indexer.query_tensors(qb[i % B], k=k, hash_times=P, seed=1000 + i, check=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        indexer.query_tensors(qb[i % B], k=k, hash_times=P, seed=1000 + i, check=False, events=ev[i])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    n_tasks, overflow = (int(v) for v in indexer.last_status.cpu())
+    assert overflow == 0, f"{tag}: task table overflow inside the timed region"
+    scan_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    sums = [batch_sums(indexer, qb[i % B], k, P, 1000 + i) for i in range(steps)]
+    sum_c, uniq_rows = float(np.mean([s_[0] for s_ in sums])), float(np.mean([s_[1] for s_ in sums]))
+    algo = int(indexer.last_algo)
+    kernel = {0: "scan_kernel (query-major)", 1: "bscan2_kernel (bucket-major, 8 queries in registers)", 2: "bscan3_kernel (bucket-major, LDS-tiled)"}[algo] + " " + metric
+    roof = bucket_major_roofline(kernel, metric, d, sum_c, uniq_rows, scan_ms * 1e-3)
+    traffic, _, _, src, dram = traffic_entry(f"{w['workload']}:{w['data']}:exact", (N, d, Q, H, P, algo, int(indexer.last_window)), True)
+    roof.update({"traffic": traffic, "traffic_source": src, "avg_launch_ms": scan_ms, "tasks_per_launch": n_tasks})
+    if dram is not None:
+        roof["dram_bytes_per_launch"] = dram
+    gt = brute_force_topk(qb[0], corpus, k, metric).cpu().numpy()
+    ids0, nc0 = indexer.query(qb[0], k=k, hash_times=P, seed=5000)
+    stats = indexer.bucket_stats()
+    out = {"workload": f"{w['cfg']}, N={N} d={d} Q={Q} H={H} k={k} hash_times={P}, {B} query batches in rotation",
+           "hash": f"learned (checkpoints/{w['ckpt']})", "steps": steps, "warmup": warmup,
+           "scan_ms": scan_ms, "device_resident_ms_per_step": 1e3 * el / steps, "device_resident_qps": Q * steps / el,
+           "recall_at_10": float(np.mean(calculate_recall(list(gt), ids0))), "mean_candidates_per_query": float(np.mean(nc0)),
+           "n_buckets": stats["n_indexes"], "window_rows": int(indexer.last_window), "roofline": roof}
+    del indexer, corpus, qb
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -516,17 +641,10 @@ def main():
     # HBM traffic / VALU instruction counts per launch: PMC numbers cannot be collected from inside the process; they
     # come from the committed rocprofv3 --pmc passes of this round (taken on the PROFILE box, same workload) when the
     # workload matches, and are labelled as such.
-    traffic, valu_insts, traffic_src, clock_held = None, None, None, None
-    try:
-        tr = json.load(open(TRAFFIC_FILE))
-        ent = tr["entries"].get(f"{args.workload}:{args.data}:{args.l2_form}")
-        if ent is not None and world == 1 and "learned" in hash_desc and tr.get("kernel_source_sha256") == kernel_source_hash():
-            w = ent["workload"]
-            if (w["N"], w["d"], w["Q"], w["H"], w["hash_times"], w["algo"], w["window_rows"]) == (N, d, Q, H, P, int(indexer.last_algo), int(indexer.last_window)):
-                traffic, valu_insts, clock_held = ent["traffic_bytes_per_launch"], ent.get("valu_wave_instructions_per_launch"), ent.get("clock_held_GHz")
-                traffic_src = "profiles/" + os.path.basename(TRAFFIC_FILE) + " (rocprofv3 --pmc on the profile box, same workload, schedule and kernel sources; not this run)"
-    except (OSError, KeyError, ValueError, TypeError):
-        pass
+    traffic, valu_insts, clock_held, traffic_src, dram_bytes = (None,) * 5
+    if world == 1:
+        traffic, valu_insts, clock_held, traffic_src, dram_bytes = traffic_entry(
+            f"{args.workload}:{args.data}:{args.l2_form}", (N, d, Q, H, P, int(indexer.last_algo), int(indexer.last_window)), "learned" in hash_desc)
 
     result = None
     if rank == 0:
@@ -576,6 +694,8 @@ def main():
                      "algorithmic_flops_per_launch": algo_flops, "sum_candidates_per_launch": sum_c_local, "tasks_per_launch": n_tasks})
         if traffic:
             roof["hbm_frac_of_measured_traffic"] = traffic / t_scan / 1e9 / HBM_PEAK_GBPS
+        if dram_bytes is not None:
+            roof["dram_bytes_per_launch"] = dram_bytes
         if valu_insts:
             roof["valu_wave_instructions_per_launch"] = valu_insts
             roof["valu_issue_frac"] = valu_insts * 2.0 / (1024 * t_scan * 2.4e9)
@@ -640,6 +760,14 @@ def main():
             result["encoder"] = enc
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, corpus_h, batches_h[0], Ws, bs, indexer, qb[0], metric)
+        side_ok = (world == 1 and not args.no_side_workloads and args.workload == "sift1m" and args.data == "manifold" and not args.dataset
+                   and not args.n and not args.dim and not args.hash_size and args.l2_form == "exact" and args.algo is None and args.window is None)
+        if side_ok:
+            # the other two workloads the round's numbers are quoted on, driver-run like the headline; `folded` is
+            # `l2_folded_opt_in` above (the headline's own index with the 2-op L2 form)
+            del indexer, shard
+            torch.cuda.empty_cache()
+            result["workloads"] = {tag: side_workload(tag, args, dev) for tag in ("glove", "clusters")}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -34,8 +34,9 @@ struct EncPlan {
     int form;        // ENC_FORM_*
     unsigned grid;
     size_t lds;
+    unsigned n32;    // ENC_FORM_HET: workgroups [0, n32) take 32 rows each, the rest 16 each
 };
-enum { ENC_FORM_H16 = 0, ENC_FORM_SINGLE, ENC_FORM_SINGLE_WIDE, ENC_FORM_BUILD128, ENC_FORM_PINGPONG, ENC_FORM_COUNT };
+enum { ENC_FORM_H16 = 0, ENC_FORM_SINGLE, ENC_FORM_SINGLE_WIDE, ENC_FORM_BUILD128, ENC_FORM_PINGPONG, ENC_FORM_HET, ENC_FORM_COUNT };
 
 int encode_plan_fill(EncPlan &p, int64_t n, int n_layers, const int *dims, const float *packed, int act, int key_mode, int n_probes,
                      int64_t n_multi_rows, int64_t row0, float *z_out, float *probs_out, uint32_t *code_out, int32_t *keys_out,

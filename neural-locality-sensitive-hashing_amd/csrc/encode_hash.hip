@@ -64,6 +64,12 @@ constexpr size_t ENC_LDS_LIMIT = 160 * 1024 - 256;
 #endif
 // Batches of at most this many rows take the 16-row form (H16): as long as its workgroups are at most one per CU (256 x 16 rows) it is
 // the shorter critical path (24.5 us against 27.2 for the 32-row form, 64 ... 4096 rows); beyond that it loses -- see the kernel.
+#ifndef NLSH_ENC_HET_PRIO
+#define NLSH_ENC_HET_PRIO 3   // wave priority of the 16-row workgroups of the balanced query-batch launch (-1: leave it alone)
+#endif
+#ifndef NLSH_ENC_HET
+#define NLSH_ENC_HET 1   // 0: every query batch of more than 4096 rows as 32-row workgroups (r02-r05), for A/B
+#endif
 #ifndef NLSH_ENC_H16_MAX_ROWS
 #define NLSH_ENC_H16_MAX_ROWS 4096
 #endif
@@ -73,6 +79,12 @@ constexpr size_t ENC_LDS_LIMIT = 160 * 1024 - 256;
 // Diagnostic build only (make EXTRA=-DNLSH_ENC_TRACE, tools/enc_trace.py): thread 0 of every workgroup
 // leaves the 100 MHz wall_clock64 stamp of each phase boundary in the first floats of its z_out rows.
 #ifdef NLSH_ENC_TRACE
+// r06: the stamps of every workgroup also land in a global table (16 floats per workgroup: stamps 0..11 relative to stamp 0, [12] the
+// workgroup's start on the launch's clock, [13] rows), readable whatever outputs the call asked for (tools/enc_step_trace.py: the
+// fused encode + lookup launch of a query batch has no z_out)
+#define NLSH_ENC_TRACE_SLOTS 4096
+__device__ float g_enc_trace[NLSH_ENC_TRACE_SLOTS * 16];
+extern "C" int nlsh_debug_enc_trace(float *host, int n_floats) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_enc_trace), (size_t)n_floats * 4); }
 #define ENC_STAMP(i) do { if (tid == 0) stamp[i] = wall_clock64(); } while (0)
 #else
 #define ENC_STAMP(i) do { } while (0)
@@ -90,13 +102,13 @@ constexpr size_t ENC_LDS_LIMIT = 160 * 1024 - 256;
 // weights whatever its rows, a 16x16x4 tile needs twice the operand bytes per flop of a 32x32x2 one, and each further 16-row
 // workgroup on a CU adds 12.5 us (24.5 / 36.9 / 47.4 / 62.0 us at 1 / 2 / 3 / 4 per CU) where a second 32-row one adds 14 for twice
 // the rows.  It IS the shorter critical path while there is at most one workgroup per CU: batches of <= 4096 rows (24.5 vs 27.2 us).
-template <int RT, int NW, bool SINGLE, int MT = 1, int WPE = 1, bool H16 = false>  // MT: column tiles a wave may own in SINGLE mode (1: width <= 32*NW); WPE: waves per SIMD the registers must allow
-__global__ __launch_bounds__(NW * 64, WPE) void encode_hash_kernel(EncArgs a, PlanArgs pa) {
+// The workgroup body: rows [row_base, row_base + M) of the batch.  `blk` = the workgroup's index in the launch (its entry of the
+// lookup's `hits`; workgroup 0 does the batch's initialisation).
+template <int RT, int NW, bool SINGLE, int MT = 1, bool H16 = false>  // MT: column tiles a wave may own in SINGLE mode (1: width <= 32*NW)
+__device__ __forceinline__ void encode_hash_body(const EncArgs &a, const PlanArgs &pa, float *smem, const long long row_base, const unsigned blk) {
     constexpr int M = H16 ? 16 * RT : 32 * RT;   // H16: RT row tiles of 16 sharing every B fragment (shipped: RT = 1; RT = 3 measured and dropped in r05)
     static_assert(!H16 || SINGLE, "the 16-row-tile form runs on a single LDS image");
     constexpr int NTH = NW * 64;
-    extern __shared__ float4 smem4[];
-    float *smem = reinterpret_cast<float *>(smem4);
     const int S = a.S;
     float *in = smem;
     float *out = SINGLE ? smem : smem + (size_t)M * S;
@@ -106,9 +118,9 @@ __global__ __launch_bounds__(NW * 64, WPE) void encode_hash_kernel(EncArgs a, Pl
     const int wave = tid >> 6;
     const int lr = lane & 31;   // row (A) / column (B, C) inside a 32x32 tile
     const int lh = lane >> 5;   // k parity (A, B) / row-quad select (C)
-    const long long row_base = (long long)blockIdx.x * M;
 #ifdef NLSH_ENC_TRACE
-    __shared__ unsigned long long stamp[12];   // LDS, not registers: twelve 64-bit values in thread 0 changed the 128-row form's allocation
+    __shared__ unsigned long long stamp[12];
+    if (tid == 0) for (int i = 0; i < 12; ++i) stamp[i] = 0;   // LDS, not registers: twelve 64-bit values in thread 0 changed the 128-row form's allocation
 #endif
     ENC_STAMP(0);
 #ifdef NLSH_ENC_TRACE
@@ -457,7 +469,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void encode_hash_kernel(EncArgs a, Pl
         if (tid < pa.nco) cpre[0] = pa.uniq[(long long)tid * pa.stride];
         if (tid + NTH < pa.nco) cpre[1] = pa.uniq[(long long)(tid + NTH) * pa.stride];
         if (tid == 0) { plan_hits = 0; plan_viol = 0; }
-        if (blockIdx.x == 0) plan_batch_init(pa, tid, NTH);
+        if (blk == 0) plan_batch_init(pa, tid, NTH);
         if (pa.prep_metric >= 0)   // the tiled schedule's padded / pre-normalised query copy of this workgroup's rows
             for (int r = wave; r < M; r += NW)
                 if (row_base + r < a.n) prep_query(pa, row_base + r, lane);
@@ -539,6 +551,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void encode_hash_kernel(EncArgs a, Pl
             if ((m >> j) & 1ull) cbuf[r * NP + __popcll(m & ((1ull << j) - 1ull))] = kbuf[e];
         }
         __syncthreads();
+        ENC_STAMP(10);
         int nhit = 0, viol = 0;
         for (int e = tid; e < M * NP; e += NTH) {
             const int r = e / NP, j = e - r * NP;
@@ -559,7 +572,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void encode_hash_kernel(EncArgs a, Pl
             for (int m = 32; m >= 1; m >>= 1) { nhit += __shfl_xor(nhit, m); viol |= __shfl_xor(viol, m); }
             if (lane == 0 && (nhit | viol)) { atomicAdd(&plan_hits, nhit); atomicOr(&plan_viol, viol); }
             __syncthreads();
-            if (tid == 0) pa.hits[blockIdx.x] = plan_hits | plan_viol;
+            if (tid == 0) pa.hits[blk] = plan_hits | plan_viol;
         }
     } else if (tid < M) {   // more than 64 probes (eval.py:148 sweeps to 100; never scanned in one call): the serial form
         const int r = tid;
@@ -578,11 +591,48 @@ __global__ __launch_bounds__(NW * 64, WPE) void encode_hash_kernel(EncArgs a, Pl
         }
     }
 #ifdef NLSH_ENC_TRACE
-    ENC_STAMP(10);
-    if (tid == 0 && a.z_out && row_base + M <= a.n)
-        for (int i = 0; i <= 10; ++i) a.z_out[row_base * H + i] = (float)(stamp[i] - stamp[0]);
-    if (tid == 0 && a.z_out && row_base + M <= a.n) a.z_out[row_base * H + 11] = (float)(__builtin_amdgcn_s_memtime() - core0);
+    __syncthreads();
+    ENC_STAMP(11);
+    if (tid == 0 && a.z_out && row_base + M <= a.n) {
+        for (int i = 0; i <= 9; ++i) a.z_out[row_base * H + i] = (float)(stamp[i] - stamp[0]);
+        a.z_out[row_base * H + 10] = (float)(stamp[11] - stamp[0]);
+        a.z_out[row_base * H + 11] = (float)(__builtin_amdgcn_s_memtime() - core0);
+    }
+    if (tid == 0 && blk < NLSH_ENC_TRACE_SLOTS) {
+        for (int i = 0; i <= 11; ++i) g_enc_trace[blk * 16 + i] = (float)(stamp[i] - stamp[0]);
+        g_enc_trace[blk * 16 + 12] = (float)(stamp[0] & 0xFFFFFFull);
+        g_enc_trace[blk * 16 + 13] = (float)M;
+    }
 #endif
+}
+
+template <int RT, int NW, bool SINGLE, int MT = 1, int WPE = 1, bool H16 = false>  // WPE: waves per SIMD the registers must allow
+__global__ __launch_bounds__(NW * 64, WPE) void encode_hash_kernel(EncArgs a, PlanArgs pa) {
+    extern __shared__ float4 smem4[];
+    encode_hash_body<RT, NW, SINGLE, MT, H16>(a, pa, reinterpret_cast<float *>(smem4), (long long)blockIdx.x * (H16 ? 16 * RT : 32 * RT), blockIdx.x);
+}
+
+// r06, the balanced query batch: 313 32-row workgroups on 256 CUs left 57 CUs with two of them, and the launch lasts as long as its
+// busiest CU (8192 rows 27 us, 8193 rows 36 us).  Here the rows of the batch's last, partial round of 32-row workgroups -- at most half
+// a round -- are dealt as 16-ROW workgroups of the all-16x16x4 form IN THE SAME GRID: workgroups [0, n32) take 32 rows each, the rest
+// 16 each, so the busiest CUs host 32 + 16 rows instead of 32 + 32 (the layers are bound by the CU's MFMA pipes: 3.7 + 7.4 us of
+// pipe time per 32-row workgroup at width 256, half of that per 16-row one).  Under the reference's batching rule (F6) the tail rows
+// are also the single-probe ones: no Philox draws, one lookup per row.  Same arithmetic per row in both bodies, so the split changes
+// no bit; the register allocation is the larger of the two bodies (87 VGPRs: two workgroups per CU, which is all the launch wants).
+__global__ __launch_bounds__(512, 1) void encode_hash_het_kernel(EncArgs a, PlanArgs pa, unsigned n32) {
+    extern __shared__ float4 smem4[];
+    if (blockIdx.x < n32) {
+        encode_hash_body<1, 8, true, 1, false>(a, pa, reinterpret_cast<float *>(smem4), (long long)blockIdx.x * 32, blockIdx.x);
+    } else {
+        // A 16-row workgroup shares its CU with a 32-row one whose waves are older: at equal priority they keep the MFMA pipes, the
+        // 16-row workgroup's first layer ends when the other's SECOND does (traced: 19 us for 1.9 us of pipe time) and its serial
+        // tail -- output layer, key pass, lookup: 11 us -- then runs alone at the end of the launch.  With the higher issue priority
+        // the short workgroup goes first and the long one's layers absorb the delay (tools/enc_step_trace.py).
+#if NLSH_ENC_HET_PRIO >= 0
+        __builtin_amdgcn_s_setprio(NLSH_ENC_HET_PRIO);
+#endif
+        encode_hash_body<1, 8, true, 2, true>(a, pa, reinterpret_cast<float *>(smem4), (long long)n32 * 32 + (long long)(blockIdx.x - n32) * 16, blockIdx.x);
+    }
 }
 
 // packed[w_off + ((nt*nch + c)*64 + lane)*4 + i] = W[nt*32 + (lane&31)][8c + 2i + (lane>>5)]
@@ -719,6 +769,20 @@ extern "C" int nlsh_pack_codes(const int32_t *codes, int64_t B, int n, int H, in
 
 namespace nlsh {
 
+// compute units of the current device (256 on MI355X), asked once
+static int device_cus() {
+    static std::atomic<int> cached{0};
+    int v = cached.load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        n = 256;     // no device visible (a CPU-only build check): the part this library is built for
+    }
+    cached.store(n, std::memory_order_relaxed);
+    return n;
+}
+
 int encode_plan_fill(EncPlan &p, int64_t n, int n_layers, const int *dims, const float *packed, int act, int key_mode, int n_probes,
                      int64_t n_multi_rows, int64_t row0, float *z_out, float *probs_out, uint32_t *code_out, int32_t *keys_out,
                      int32_t *nkeys_out) {
@@ -742,7 +806,7 @@ int encode_plan_fill(EncPlan &p, int64_t n, int n_layers, const int *dims, const
     a.H = dims[n_layers]; a.act = act; a.key_mode = key_mode; a.n_probes = n_probes;
     a.n_multi_rows = n_multi_rows; a.row0 = row0; a.seed = 0;
     a.z_out = z_out; a.probs_out = probs_out; a.code_out = code_out; a.keys_out = keys_out; a.nkeys_out = nkeys_out;
-    p.form = ENC_FORM_SINGLE; p.grid = 0; p.lds = 0;
+    p.form = ENC_FORM_SINGLE; p.grid = 0; p.lds = 0; p.n32 = 0;
     if (n == 0) return NLSH_OK;
 
     const size_t lds_limit = ENC_LDS_LIMIT;
@@ -762,6 +826,14 @@ int encode_plan_fill(EncPlan &p, int64_t n, int n_layers, const int *dims, const
             p.form = ENC_FORM_H16; p.lds = (size_t)16 * a.S * 4; p.grid = (unsigned)((n + 15) / 16);
         } else if (max_np <= 32 * 8) {
             p.form = ENC_FORM_SINGLE;
+            // the rows behind the last FULL round of 32-row workgroups (one per CU), when they are at most half a round, as 16-row
+            // workgroups of the same launch (encode_hash_het_kernel): 10^4 rows on 256 CUs = 256 x 32 + 113 x 16
+            const long long round_rows = 32ll * device_cus(), rem = n % round_rows;
+            if (NLSH_ENC_HET && h16_ok && n > round_rows && rem > 0 && rem <= round_rows / 2) {
+                p.form = ENC_FORM_HET;
+                p.n32 = (unsigned)((n - rem) / 32);
+                p.grid = p.n32 + (unsigned)((rem + 15) / 16);
+            }
         } else {
             p.form = ENC_FORM_SINGLE_WIDE;
         }
@@ -801,7 +873,7 @@ static int allow_lds(int form, const void *fn) {
 
 // rows per workgroup of a kernel form
 static int form_rows(int form) {
-    return form == ENC_FORM_H16 ? 16 : form == ENC_FORM_BUILD128 ? 128 : form == ENC_FORM_PINGPONG ? 64 : 32;
+    return (form == ENC_FORM_H16 || form == ENC_FORM_HET) ? 16 : form == ENC_FORM_BUILD128 ? 128 : form == ENC_FORM_PINGPONG ? 64 : 32;   // HET: its smaller workgroups
 }
 
 // The bucket lookup of the scan's PLAN phase in this launch's epilogue (scan_plan.h): sizes the coarse key table for the LDS the form
@@ -819,7 +891,7 @@ int encode_plan_fuse_lookup(EncPlan &p, PlanArgs &pa) {
     const int want = pa.nb < 256 ? (pa.nb > 0 ? pa.nb : 1) : 256;
     if (cap < want) {
         p.a.S = round_up(used + (want + M - 1) / M, 8) + 4;       // S / 4 stays odd (conflict-free A-fragment reads)
-        p.lds = (size_t)(pingpong ? 2 : 1) * M * p.a.S * 4;
+        p.lds = (size_t)(pingpong ? 2 : 1) * (p.form == ENC_FORM_HET ? 32 : M) * p.a.S * 4;
         NLSH_REQUIRE(p.lds <= ENC_LDS_LIMIT, NLSH_E_UNSUPPORTED, "encode_hash + lookup: %zu B of LDS", p.lds);
         cap = M * (p.a.S - used);
     }
@@ -855,6 +927,11 @@ int encode_plan_launch(const EncPlan &p, const float *x, int64_t x_stride, uint6
         NLSH_ENC_LAUNCH(ENC_FORM_SINGLE_WIDE, 1, 8, true, 3)
         NLSH_ENC_LAUNCH(ENC_FORM_BUILD128, 4, 8, true, 1)
         NLSH_ENC_LAUNCH(ENC_FORM_PINGPONG, 2, 8, false, 1)
+        case ENC_FORM_HET: {
+            int rc = allow_lds(ENC_FORM_HET, (const void *)encode_hash_het_kernel);
+            if (rc != NLSH_OK) return rc;
+            hipLaunchKernelGGL(encode_hash_het_kernel, dim3(p.grid), dim3(512), p.lds, s, a, pa, p.n32);
+        } break;
         default: NLSH_REQUIRE(false, NLSH_E_INVALID, "encode_hash: form %d", p.form);
     }
 #undef NLSH_ENC_LAUNCH

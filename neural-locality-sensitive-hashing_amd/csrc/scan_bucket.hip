@@ -971,30 +971,41 @@ __device__ __forceinline__ void merge_query(const BArgs &a, long long q, int lan
     const int L = __builtin_amdgcn_readlane(incl, 63);
     const int R = 64 / a.k;
     const int r = lane / a.k, e = lane - r * a.k;
-    uint64_t carry = KEY_NONE;
-    for (int base = 0; base < L; base += 3 * R) {
-        uint64_t key[4];
-        key[0] = carry;
+    // keys of list slot `li` (one list per group of k lanes): which probe it belongs to, which segment of that probe's bucket
+    auto fetch = [&](int li) -> uint64_t {
+        int lo = 0, hi = 63;  // probe of list li = first lane whose inclusive count exceeds li
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const int li = base + s * R + r;
-            int lo = 0, hi = 63;  // probe of list li = first lane whose inclusive count exceeds li
-#pragma unroll
-            for (int step = 0; step < 6; ++step) {
-                const int mid = (lo + hi) >> 1;
-                if (__shfl(incl, mid) > li) hi = mid; else lo = mid + 1;
-            }
-            const int p = lo > 63 ? 63 : lo;
-            const int si = li - (__shfl(incl, p) - __shfl(ns_l, p));
-            const long long t = (long long)(((unsigned long long)(unsigned)__shfl((int)(t0_l >> 32), p) << 32) | (unsigned)__shfl((int)t0_l, p)) +
-                                (long long)si * __shfl(ng_l, p);
-            const int j = __shfl(j_l, p);
-            // t >= max_tasks: table overflow, status[1] was set by the scan kernel and the caller repeats the call
-            const bool live = r < R && li < L && t < a.max_tasks;
-            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.partial) + ((live ? t : 0) * a.QB + j) * a.k + e;
-            key[s + 1] = live ? (uint64_t)*src : KEY_NONE;
+        for (int step = 0; step < 6; ++step) {
+            const int mid = (lo + hi) >> 1;
+            if (__shfl(incl, mid) > li) hi = mid; else lo = mid + 1;
         }
-        carry = merge_round<4>(key, a.k, lane, sc);
+        const int p = lo > 63 ? 63 : lo;
+        const int si = li - (__shfl(incl, p) - __shfl(ns_l, p));
+        const long long t = (long long)(((unsigned long long)(unsigned)__shfl((int)(t0_l >> 32), p) << 32) | (unsigned)__shfl((int)t0_l, p)) +
+                            (long long)si * __shfl(ng_l, p);
+        const int j = __shfl(j_l, p);
+        // t >= max_tasks: table overflow, status[1] was set by the scan kernel and the caller repeats the call
+        const bool live = r < R && li < L && t < a.max_tasks;
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.partial) + ((live ? t : 0) * a.QB + j) * a.k + e;
+        return live ? (uint64_t)*src : KEY_NONE;
+    };
+    uint64_t carry = KEY_NONE;
+    if (L <= R) {
+        // r06: a query with at most R lists (GloVe-shaped: 6.5 probed buckets of a few rows each) selects from ONE key per lane -- a
+        // quarter of the ballots per bisection step of the general round and one list lookup instead of three; <= 2R lists: two
+        uint64_t key[1] = {fetch(r)};
+        carry = merge_round<1>(key, a.k, lane, sc);
+    } else if (L <= 2 * R) {
+        uint64_t key[2] = {fetch(r), fetch(R + r)};
+        carry = merge_round<2>(key, a.k, lane, sc);
+    } else {
+        for (int base = 0; base < L; base += 3 * R) {
+            uint64_t key[4];
+            key[0] = carry;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) key[s + 1] = fetch(base + s * R + r);
+            carry = merge_round<4>(key, a.k, lane, sc);
+        }
     }
     merge_finish(carry, a.k, lane, a.out_dist, a.out_idx, a.out_keys, q);
 }

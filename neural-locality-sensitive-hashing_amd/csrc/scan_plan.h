@@ -81,7 +81,7 @@ __device__ __forceinline__ void plan_batch_init(const PlanArgs &a, int tid, int 
 }
 
 // One (query, probe) pair: binary search of `key` in uniq[nb] -- the first steps on the coarse table in LDS (every stride-th key),
-// the last log2(stride) on the stride-long run in global memory: 3-7 dependent global loads instead of 13-17 -- then the bucket's
+// the last ones on the stride-long run in global memory: 1-5 dependent global round trips instead of 13-17 -- then the bucket's
 // rows, its cell, and the slot the pair takes in the cell's list.  `live` = the slot holds a key at all (p < nkeys[q], not a repeat).
 // Returns true when the pair was counted; `viol` collects PLAN_VIOL_* flags.
 __device__ __forceinline__ bool plan_pair(const PlanArgs &a, const int32_t *coarse, long long idx, int32_t key, bool live, int &viol) {
@@ -96,11 +96,23 @@ __device__ __forceinline__ bool plan_pair(const PlanArgs &a, const int32_t *coar
         if (lo > 0) {  // the key, if present, lies in the run that starts at coarse entry lo-1
             lo = (lo - 1) * a.stride;
             hi = min(a.nb, lo + a.stride);
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (a.uniq[mid] < key) lo = mid + 1; else hi = mid;
+            // r06: the run is narrowed by bisection over its BLOCKS of 8 keys (first key of each), and the last block's 8 keys are
+            // requested together -- one dependent round trip for the final three bisection steps and the equality test behind them
+            // (headline index: stride 8, so the whole fine search is ONE round trip instead of four).  The lookup sits in the tail of
+            // a latency-bound workgroup (encode_hash's epilogue): dependent round trips are what it costs.
+            int blo = lo >> 3, bhi = (hi + 7) >> 3;     // runs start at multiples of the stride, a power of two >= 8 or the whole table
+            while (bhi - blo > 1) {                      // last block whose first key is <= key
+                const int mid = (blo + bhi) >> 1;
+                if (a.uniq[mid << 3] <= key) blo = mid; else bhi = mid;
             }
-            if (lo < a.nb && a.uniq[lo] == key) {  // unknown key = empty bucket (indexer.py:61,68)
+            const int base = blo << 3;
+            int32_t kk[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kk[j] = a.uniq[min(base + j, a.nb - 1)];
+            lo = a.nb;
+#pragma unroll
+            for (int j = 7; j >= 0; --j) lo = (kk[j] == key && base + j < a.nb) ? base + j : lo;
+            if (lo < a.nb) {  // unknown key = empty bucket (indexer.py:61,68)
                 const int row0 = a.offsets[lo], size = a.offsets[lo + 1] - row0;
                 if (size > 0) {
                     const int c = a.cell_of ? a.cell_of[lo] : lo;

@@ -12,7 +12,7 @@ PMC="FETCH_SIZE SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_C
 pmc_bench() {   # $1 = tag, rest = bench.py flags: counters of the bench command in their own pass (no tracing domains beside --pmc)
   tag=$1; shift
   rm -rf /tmp/pm_$tag
-  (cd /tmp && TMPDIR=/tmp rocprofv3 --pmc $PMC --output-format csv -d /tmp/pm_$tag -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 --query-chunks 1 "$@" > $O/pmc_${tag}_line.json 2> /tmp/pm_$tag.err)
+  (cd /tmp && TMPDIR=/tmp rocprofv3 --pmc $PMC --output-format csv -d /tmp/pm_$tag -- python3 $R/bench.py --no-cpu-baseline --no-side-workloads --steps 3 --warmup 1 --query-chunks 1 "$@" > $O/pmc_${tag}_line.json 2> /tmp/pm_$tag.err)
   python3 $R/tools/pmc_summary.py /tmp/pm_$tag > $O/pmc_$tag.json
 }
 if [ "${1:-main}" = "main" ]; then
@@ -29,7 +29,7 @@ if [ "${1:-main}" = "main" ]; then
     CLK=$(grep -oE 'clock median [0-9.]+' $O/scan_clock.txt | head -1 | awk '{print $3}')
   fi
   # per-kernel statistics of the bench command (one row range per query() call: every scan launch has the full-batch grid)
-  rm -rf /tmp/kt && (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --no-cpu-baseline --query-chunks 1 > $O/bench_under_rocprof.json 2> /tmp/kt.err)
+  rm -rf /tmp/kt && (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --no-cpu-baseline --no-side-workloads --query-chunks 1 > $O/bench_under_rocprof.json 2> /tmp/kt.err)
   cp $(find /tmp/kt -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
   python3 $R/tools/kernel_trace_regions.py /tmp/kt > $O/kernel_trace_regions.txt
   rm -rf /tmp/kts && (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --output-format csv -d /tmp/kts -- python3 $R/tools/step_timeline.py > /dev/null 2> /tmp/kts.err)

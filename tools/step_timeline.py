@@ -28,8 +28,9 @@ if len(sys.argv) > 2 and sys.argv[1] == "--parse":
             if "nlsh::" in n:
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n.split("nlsh::")[1].split("(")[0].split("<")[0]))
     rows.sort()
-    first = rows[0][2] if not any(r[2] == "encode_hash_kernel" for r in rows) else "encode_hash_kernel"
-    starts = [i for i, r in enumerate(rows) if r[2] == first]
+    # a step starts at its encode launch (r06: the query batch's form has a kernel name of its own, encode_hash_het_kernel)
+    first = rows[0][2] if not any(r[2].startswith("encode_hash") for r in rows) else None
+    starts = [i for i, r in enumerate(rows) if (r[2] == first if first else r[2].startswith("encode_hash"))]
     steps = [rows[a:b] for a, b in zip(starts[:-1], starts[1:])][-20:]
     names = [r[2] for r in steps[-1]]
     steps = [s for s in steps if [r[2] for r in s] == names]
