@@ -284,6 +284,13 @@ typedef struct nlsh_step_desc {
 
 /* desc_bytes = sizeof(nlsh_step_desc_t) of the CALLER's header: a binding built against another layout is refused. */
 int nlsh_step_create(const nlsh_step_desc_t *desc, size_t desc_bytes, nlsh_step_t **step_out);
+/* A GRAPH slot (r06): the batch's five launches are captured once into a hipGraph and replayed on `lane`, the slot's OWN stream (a real
+ * stream, different for every slot; the four stream handles of `desc` are ignored).  nlsh_query_step_enqueue is then one graph launch,
+ * two kernel-node updates (the batch pointer / row stride / seed of the encode, the query pointer of the scan) and one event record --
+ * a third of the runtime calls of a staged slot.  Batches of different slots overlap because their lanes do; consecutive batches of one
+ * slot are ordered by its lane.  hold_done: the caller's extra work goes on `lane`.  A call with scan events is launched eagerly on the
+ * lane (same kernels).  Bucket-major schedules only (algo 1, 2).  Same results as the staged slots and the separate calls, bit for bit. */
+int nlsh_step_create_graph(const nlsh_step_desc_t *desc, size_t desc_bytes, nlsh_stream_t lane, nlsh_step_t **step_out);
 int nlsh_step_destroy(nlsh_step_t *step);
 /* New packed weights (nlsh_encoder_pack) for the batches enqueued from now on (a training step between two batches). */
 int nlsh_step_set_weights(nlsh_step_t *step, const float *packed);

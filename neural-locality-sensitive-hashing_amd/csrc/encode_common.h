@@ -46,5 +46,8 @@ struct PlanArgs;   // scan_plan.h: the bucket lookup of the scan's PLAN phase, o
 // encode_plan_fuse_lookup -- the scan call then runs NLSH_PHASE_PLAN_REST instead of NLSH_PHASE_PLAN.
 int encode_plan_launch(const EncPlan &p, const float *x, int64_t x_stride, uint64_t seed, hipStream_t s, const PlanArgs *lookup = nullptr);
 int encode_plan_fuse_lookup(EncPlan &p, PlanArgs &pa);
+// One-time, per (device, kernel form) set-up of the launch (the dynamic-LDS permission): called by encode_plan_launch itself; callers
+// that CAPTURE the launch into a hipGraph call it before the capture starts.
+int encode_plan_prepare(const EncPlan &p);
 
 }  // namespace nlsh

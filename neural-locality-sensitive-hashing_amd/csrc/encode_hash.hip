@@ -25,8 +25,7 @@
 //     MSB-first packing, Philox Bernoulli probes and per-row de-duplication are the epilogue.
 #include <atomic>
 
-#include "encode_common.h"
-#include "scan_plan.h"
+#include "step_nodes.h"
 
 namespace nlsh {
 
@@ -900,42 +899,54 @@ int encode_plan_fuse_lookup(EncPlan &p, PlanArgs &pa) {
     return NLSH_OK;
 }
 
+// the kernel of a form (one instantiation each)
+static const void *form_kernel(int form) {
+    switch (form) {
+        case ENC_FORM_H16: return (const void *)encode_hash_kernel<1, 8, true, 2, 1, true>;
+        case ENC_FORM_SINGLE: return (const void *)encode_hash_kernel<1, 8, true, 1>;
+        case ENC_FORM_SINGLE_WIDE: return (const void *)encode_hash_kernel<1, 8, true, 3>;
+        case ENC_FORM_BUILD128: return (const void *)encode_hash_kernel<4, 8, true, 1>;
+        case ENC_FORM_PINGPONG: return (const void *)encode_hash_kernel<2, 8, false, 1>;
+        case ENC_FORM_HET: return (const void *)encode_hash_het_kernel;
+        default: return nullptr;
+    }
+}
+
+int encode_plan_prepare(const EncPlan &p) {
+    const void *fn = form_kernel(p.form);
+    NLSH_REQUIRE(fn != nullptr, NLSH_E_INVALID, "encode_hash: form %d", p.form);
+    return p.a.n == 0 ? NLSH_OK : allow_lds(p.form, fn);
+}
+
+int encode_plan_node(const EncPlan &p, const float *x, int64_t x_stride, uint64_t seed, const PlanArgs *lookup, EncNode *out) {
+    NLSH_REQUIRE(p.a.n > 0 && x != nullptr && out != nullptr, NLSH_E_INVALID, "encode_hash: null pointer");
+    NLSH_REQUIRE(x_stride >= p.a.L[0].K, NLSH_E_INVALID, "encode_hash: x_stride %lld < d %d", (long long)x_stride, p.a.L[0].K);
+    out->a = p.a;
+    out->a.x = x; out->a.x_stride = x_stride; out->a.seed = seed;
+    if (lookup) {
+        out->pa = *lookup;
+        out->pa.queries = x; out->pa.q_stride = x_stride;   // the batch itself (the padded query copy is made from it)
+    } else {
+        out->pa = PlanArgs{};
+        out->pa.enabled = 0; out->pa.prep_metric = -1;
+    }
+    out->n32 = p.n32;
+    out->argv[0] = &out->a; out->argv[1] = &out->pa; out->argv[2] = &out->n32;
+    out->p = hipKernelNodeParams{};
+    out->p.func = const_cast<void *>(form_kernel(p.form));
+    NLSH_REQUIRE(out->p.func != nullptr, NLSH_E_INVALID, "encode_hash: form %d", p.form);
+    out->p.gridDim = dim3(p.grid); out->p.blockDim = dim3(512); out->p.sharedMemBytes = (unsigned)p.lds;
+    out->p.kernelParams = out->argv; out->p.extra = nullptr;
+    return NLSH_OK;
+}
+
 int encode_plan_launch(const EncPlan &p, const float *x, int64_t x_stride, uint64_t seed, hipStream_t s, const PlanArgs *lookup) {
     if (p.a.n == 0) return NLSH_OK;
-    NLSH_REQUIRE(x != nullptr, NLSH_E_INVALID, "encode_hash: null pointer");
-    NLSH_REQUIRE(x_stride >= p.a.L[0].K, NLSH_E_INVALID, "encode_hash: x_stride %lld < d %d", (long long)x_stride, p.a.L[0].K);
-    EncArgs a = p.a;
-    a.x = x; a.x_stride = x_stride; a.seed = seed;
-    PlanArgs pa;
-    if (lookup) {
-        pa = *lookup;
-        pa.queries = x; pa.q_stride = x_stride;   // the batch itself (the padded query copy is made from it)
-    } else {
-        pa = PlanArgs{};
-        pa.enabled = 0; pa.prep_metric = -1;
-    }
-#define NLSH_ENC_LAUNCH(FORM, ...)                                                                 \
-    case FORM: {                                                                                   \
-        auto *fn = encode_hash_kernel<__VA_ARGS__>;                                                \
-        int rc = allow_lds(FORM, (const void *)fn);                                                \
-        if (rc != NLSH_OK) return rc;                                                              \
-        hipLaunchKernelGGL(fn, dim3(p.grid), dim3(512), p.lds, s, a, pa);                          \
-    } break;
-    switch (p.form) {
-        NLSH_ENC_LAUNCH(ENC_FORM_H16, 1, 8, true, 2, 1, true)
-        NLSH_ENC_LAUNCH(ENC_FORM_SINGLE, 1, 8, true, 1)
-        NLSH_ENC_LAUNCH(ENC_FORM_SINGLE_WIDE, 1, 8, true, 3)
-        NLSH_ENC_LAUNCH(ENC_FORM_BUILD128, 4, 8, true, 1)
-        NLSH_ENC_LAUNCH(ENC_FORM_PINGPONG, 2, 8, false, 1)
-        case ENC_FORM_HET: {
-            int rc = allow_lds(ENC_FORM_HET, (const void *)encode_hash_het_kernel);
-            if (rc != NLSH_OK) return rc;
-            hipLaunchKernelGGL(encode_hash_het_kernel, dim3(p.grid), dim3(512), p.lds, s, a, pa, p.n32);
-        } break;
-        default: NLSH_REQUIRE(false, NLSH_E_INVALID, "encode_hash: form %d", p.form);
-    }
-#undef NLSH_ENC_LAUNCH
-    NLSH_CHECK_HIP(hipGetLastError());
+    EncNode node;
+    int rc = encode_plan_node(p, x, x_stride, seed, lookup, &node);
+    if (rc == NLSH_OK) rc = encode_plan_prepare(p);
+    if (rc != NLSH_OK) return rc;
+    NLSH_CHECK_HIP(hipLaunchKernel(node.p.func, node.p.gridDim, node.p.blockDim, node.p.kernelParams, node.p.sharedMemBytes, s));
     return NLSH_OK;
 }
 

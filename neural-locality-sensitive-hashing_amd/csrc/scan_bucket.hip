@@ -22,8 +22,9 @@
 //   bscan2 | bscan3: partial top-k per (task, query)
 //   bmerge   wave/query: merge the partial lists of its (probe, segment) pairs -> final top-k
 // Results do not depend on slot/task order: every list is merged with the (distance, id) comparator.
-#include "scan_common.h"
-#include "scan_plan.h"
+#include <new>
+
+#include "step_nodes.h"
 
 // Diagnostic build only (make EXTRA=-DNLSH_SCAN_TRACE, tools/scan_trace.py): wave 0 of every bscan3 workgroup
 // leaves its phase durations (100 MHz wall_clock64 ticks) in g_scan_trace; the shipped library has neither.
@@ -1368,12 +1369,32 @@ extern "C" int nlsh_scan_workspace_layout(int64_t Q, int P, int k, int64_t max_t
 namespace nlsh {
 
 template <int METRIC>
-static void launch_bscan2(const BArgs &a, int d4, unsigned grid, hipStream_t s) {
-    if (d4 <= 16) hipLaunchKernelGGL((bscan2_kernel<16, 1, METRIC, 8>), dim3(grid), dim3(256), 0, s, a);
-    else if (d4 <= 32) hipLaunchKernelGGL((bscan2_kernel<32, 1, METRIC, 8>), dim3(grid), dim3(256), 0, s, a);
-    else if (d4 <= 64) hipLaunchKernelGGL((bscan2_kernel<64, 1, METRIC, 8>), dim3(grid), dim3(256), 0, s, a);
-    else if (d4 <= 128) hipLaunchKernelGGL((bscan2_kernel<64, 2, METRIC, 4>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((bscan2_kernel<64, 4, METRIC, 2>), dim3(grid), dim3(256), 0, s, a);
+static const void *bscan2_of(int d4) {
+    if (d4 <= 16) return (const void *)bscan2_kernel<16, 1, METRIC, 8>;
+    if (d4 <= 32) return (const void *)bscan2_kernel<32, 1, METRIC, 8>;
+    if (d4 <= 64) return (const void *)bscan2_kernel<64, 1, METRIC, 8>;
+    if (d4 <= 128) return (const void *)bscan2_kernel<64, 2, METRIC, 4>;
+    return (const void *)bscan2_kernel<64, 4, METRIC, 2>;
+}
+
+// the scan kernel of a call and its launch shape
+static void scan_kernel_of(const BucketScanCall &c, int metric, int d4, const void **fn, dim3 *grid, dim3 *block) {
+    if (c.tiled) {
+        // QW = 4 queries per wave (SGPR budget: two chunks x QW x 4 scalar values in flight), NW = 4 waves
+        // one workgroup per task; the chunked XCD map works on 8 x 16 ids.  (Persistent workgroups pulling tasks from a
+        // per-XCD queue were measured three ways in r02 -- 0.447 / 0.423 / 0.350 ms against 0.283 ms; r04: 2 / 4 / 8 consecutive
+        // task ids per workgroup, 79 VGPRs, +3 / +10 / +25 % on the headline and no better on the small-bucket workloads:
+        // profiles/r04_tasks_per_workgroup_ab.txt, DESIGN.md appendix A.)
+        *grid = dim3((unsigned)((c.max_tasks + 127) / 128 * 128));
+        *block = dim3(64 * (TILED_QB / 4));
+        if (metric == NLSH_METRIC_L2_EPS) *fn = (const void *)bscan3_kernel<NLSH_METRIC_L2_EPS, 4, TILED_QB / 4, TILED_TPS>;
+        else if (metric == NLSH_METRIC_L2_EPS_FOLDED) *fn = (const void *)bscan3_kernel<NLSH_METRIC_L2_EPS_FOLDED, 4, TILED_QB / 4, TILED_TPS>;
+        else *fn = (const void *)bscan3_kernel<NLSH_METRIC_COSINE, 4, TILED_QB / 4, TILED_TPS>;
+    } else {
+        *grid = dim3((unsigned)((c.max_tasks + 3) / 4));  // one wavefront per task
+        *block = dim3(256);
+        *fn = metric == NLSH_METRIC_L2_EPS ? bscan2_of<NLSH_METRIC_L2_EPS>(d4) : bscan2_of<NLSH_METRIC_COSINE>(d4);
+    }
 }
 
 // BArgs (what the scan kernels take) and PlanArgs (what the lookup takes) of one call: pointers into the caller's workspace.
@@ -1417,6 +1438,24 @@ static int bucket_scan_args(const BucketScanCall &c, BArgs &a, PlanArgs &pa, int
     return NLSH_OK;
 }
 
+int bucket_scan_node(const BucketScanCall &c, ScanNode *out) {
+    static_assert(sizeof(BArgs) <= sizeof(out->args) && alignof(BArgs) <= 16, "ScanNode::args must hold the scan kernels' argument struct");
+    NLSH_REQUIRE(c.max_tasks > 0, NLSH_E_INVALID, "scan node: empty task table");
+    BArgs *a = new (out->args) BArgs;
+    PlanArgs pa;
+    int metric;
+    bool prep;
+    const int rc = bucket_scan_args(c, *a, pa, metric, prep);
+    if (rc != NLSH_OK) return rc;
+    const void *fn;
+    out->p = hipKernelNodeParams{};
+    scan_kernel_of(c, metric, (c.d + 3) / 4, &fn, &out->p.gridDim, &out->p.blockDim);
+    out->p.func = const_cast<void *>(fn);
+    out->argv[0] = out->args;
+    out->p.kernelParams = out->argv; out->p.sharedMemBytes = 0; out->p.extra = nullptr;
+    return NLSH_OK;
+}
+
 int bucket_scan_plan_args(const BucketScanCall &c, PlanArgs *pa) {
     BArgs a;
     int metric;
@@ -1456,21 +1495,11 @@ int bucket_scan_run(const BucketScanCall &c) {
     }
     if ((c.phases & NLSH_PHASE_SCAN) && c.max_tasks > 0) {
         if (c.ev_begin) NLSH_CHECK_HIP(hipEventRecord((hipEvent_t)c.ev_begin, s));
-        if (c.tiled) {
-            // QW = 4 queries per wave (SGPR budget: two chunks x QW x 4 scalar values in flight), NW = 4 waves
-            // one workgroup per task; the chunked XCD map works on 8 x 16 ids.  (Persistent workgroups pulling tasks from a
-            // per-XCD queue were measured three ways in r02 -- 0.447 / 0.423 / 0.350 ms against 0.283 ms; r04: 2 / 4 / 8 consecutive
-            // task ids per workgroup, 79 VGPRs, +3 / +10 / +25 % on the headline and no better on the small-bucket workloads:
-            // profiles/r04_tasks_per_workgroup_ab.txt, DESIGN.md appendix A.)
-            const unsigned grid = (unsigned)((c.max_tasks + 127) / 128 * 128);
-            if (metric == NLSH_METRIC_L2_EPS) hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_L2_EPS, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
-            else if (metric == NLSH_METRIC_L2_EPS_FOLDED) hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_L2_EPS_FOLDED, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
-            else hipLaunchKernelGGL((bscan3_kernel<NLSH_METRIC_COSINE, 4, TILED_QB / 4, TILED_TPS>), dim3(grid), dim3(64 * (TILED_QB / 4)), 0, s, a);
-        } else {
-            const unsigned grid = (unsigned)((c.max_tasks + 3) / 4);  // one wavefront per task
-            if (metric == NLSH_METRIC_L2_EPS) launch_bscan2<NLSH_METRIC_L2_EPS>(a, d4, grid, s);
-            else launch_bscan2<NLSH_METRIC_COSINE>(a, d4, grid, s);
-        }
+        const void *fn;
+        dim3 grid, block;
+        scan_kernel_of(c, metric, d4, &fn, &grid, &block);
+        void *argv[1] = {&a};
+        NLSH_CHECK_HIP(hipLaunchKernel(fn, grid, block, argv, 0, s));
         if (c.ev_end) NLSH_CHECK_HIP(hipEventRecord((hipEvent_t)c.ev_end, s));
     }
     if (c.phases & NLSH_PHASE_MERGE) hipLaunchKernelGGL(bmerge_kernel, dim3((unsigned)((c.Q + 3) / 4)), dim3(256), 0, s, a);

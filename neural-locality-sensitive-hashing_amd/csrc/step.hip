@@ -15,9 +15,7 @@
 // as a one-stream call for callers that do not pipeline (nlsh_query_batch: what `Indexer.query_tensors` issues).
 #include <new>
 
-#include "encode_common.h"
-#include "scan_common.h"
-#include "scan_plan.h"
+#include "step_nodes.h"
 
 using namespace nlsh;
 
@@ -27,6 +25,11 @@ struct nlsh_step {
     int dims[NLSH_MAX_LAYERS + 1];
     hipEvent_t ready, encoded, planned, scanned, done;
     bool done_pending;   // hold_done: the caller still has to release the batch (nlsh_step_release)
+    // graph slots (nlsh_step_create_graph): the batch's five launches captured once, replayed on `lane`
+    hipStream_t lane;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    hipGraphNode_t enc_node, scan_node;
 };
 
 // One batch's scan call as the bucket-major descriptor (validated), or -- query-major schedule -- nothing (fused = false).
@@ -63,14 +66,16 @@ static int make_event(hipEvent_t *e) {
     return NLSH_OK;
 }
 
-extern "C" int nlsh_step_create(const nlsh_step_desc_t *desc, size_t desc_bytes, nlsh_step_t **out) {
+static int step_create(const nlsh_step_desc_t *desc, size_t desc_bytes, hipStream_t lane, nlsh_step_t **out) {
     NLSH_REQUIRE(desc && out, NLSH_E_INVALID, "step_create: null pointer");
     NLSH_REQUIRE(desc_bytes == sizeof(nlsh_step_desc_t), NLSH_E_INVALID, "step_create: descriptor of %zu bytes, this library's is %zu (ABI %d)",
                  desc_bytes, sizeof(nlsh_step_desc_t), NLSH_ABI_VERSION);
-    NLSH_REQUIRE(desc->front && desc->mid && desc->tail, NLSH_E_INVALID, "step_create: the front, mid and tail streams must be real streams (not the default stream)");
-    NLSH_REQUIRE(desc->front != desc->mid && desc->mid != desc->tail && desc->front != desc->tail && desc->plan != desc->front && desc->plan != desc->mid &&
-                     desc->plan != desc->tail,
-                 NLSH_E_INVALID, "step_create: front, plan, mid and tail must be DIFFERENT streams (the stages overlap only across streams, and an event is recorded on one and waited for on the next)");
+    if (lane == nullptr) {
+        NLSH_REQUIRE(desc->front && desc->mid && desc->tail, NLSH_E_INVALID, "step_create: the front, mid and tail streams must be real streams (not the default stream)");
+        NLSH_REQUIRE(desc->front != desc->mid && desc->mid != desc->tail && desc->front != desc->tail && desc->plan != desc->front && desc->plan != desc->mid &&
+                         desc->plan != desc->tail,
+                     NLSH_E_INVALID, "step_create: front, plan, mid and tail must be DIFFERENT streams (the stages overlap only across streams, and an event is recorded on one and waited for on the next)");
+    }
     NLSH_REQUIRE(desc->n_layers >= 1 && desc->n_layers <= NLSH_MAX_LAYERS && desc->dims, NLSH_E_INVALID, "step_create: n_layers=%d", desc->n_layers);
     NLSH_REQUIRE(desc->n_probes >= 1 && desc->n_probes <= NLSH_MAX_PROBES, NLSH_E_UNSUPPORTED, "step_create: n_probes=%d not in [1,%d] (one scan call per batch)",
                  desc->n_probes, NLSH_MAX_PROBES);
@@ -83,6 +88,8 @@ extern "C" int nlsh_step_create(const nlsh_step_desc_t *desc, size_t desc_bytes,
     s->d.dims = s->dims;
     s->ready = s->encoded = s->planned = s->scanned = s->done = nullptr;
     s->done_pending = false;
+    s->lane = lane; s->graph = nullptr; s->exec = nullptr; s->enc_node = s->scan_node = nullptr;
+    const hipStream_t last = lane ? lane : (hipStream_t)desc->tail;    // the stream a batch ends on
     int rc = encode_plan_fill(s->enc, desc->Q, desc->n_layers, s->dims, desc->packed, desc->act, desc->key_mode, desc->n_probes, desc->n_multi_rows, 0,
                               nullptr, nullptr, nullptr, desc->qkeys, desc->nkeys);
     // the scan call's own argument checks (workspace alignment and size, strides, limits) run HERE, on a stand-in batch pointer, so
@@ -90,19 +97,24 @@ extern "C" int nlsh_step_create(const nlsh_step_desc_t *desc, size_t desc_bytes,
     if (rc == NLSH_OK) {
         BucketScanCall c;
         rc = scan_call(s->d, desc->corpus_sorted ? desc->corpus_sorted : (const float *)desc->workspace, desc->row_stride >= desc->d ? desc->row_stride : desc->d,
-                       nullptr, nullptr, desc->front, NLSH_PHASE_SCAN, 0, desc->algo != NLSH_SCAN_QUERY_MAJOR ? &c : nullptr);
+                       nullptr, nullptr, (nlsh_stream_t)last, NLSH_PHASE_SCAN, 0, desc->algo != NLSH_SCAN_QUERY_MAJOR ? &c : nullptr);
         if (rc == NLSH_OK && desc->algo != NLSH_SCAN_QUERY_MAJOR) {
             PlanArgs pa;
             rc = bucket_scan_plan_args(c, &pa);
             if (rc == NLSH_OK && fuses_lookup(s->d)) rc = encode_plan_fuse_lookup(s->enc, pa);
         }
     }
+    if (rc == NLSH_OK && lane != nullptr && !(fuses_lookup(s->d) && desc->max_tasks > 0)) {
+        set_error("step_create_graph: graph slots take the bucket-major schedules (algo 1, 2) on a non-empty index and task table");
+        rc = NLSH_E_UNSUPPORTED;
+    }
+    if (rc == NLSH_OK) rc = encode_plan_prepare(s->enc);     // the dynamic-LDS permission of the encode's form: not inside a capture
     if (rc == NLSH_OK) rc = make_event(&s->ready);
-    if (rc == NLSH_OK) rc = make_event(&s->encoded);
-    if (rc == NLSH_OK) rc = make_event(&s->planned);
-    if (rc == NLSH_OK) rc = make_event(&s->scanned);
+    if (rc == NLSH_OK && !lane) rc = make_event(&s->encoded);
+    if (rc == NLSH_OK && !lane) rc = make_event(&s->planned);
+    if (rc == NLSH_OK && !lane) rc = make_event(&s->scanned);
     if (rc == NLSH_OK) rc = make_event(&s->done);
-    if (rc == NLSH_OK && hipEventRecord(s->done, (hipStream_t)desc->tail) != hipSuccess) {   // the slot starts out free
+    if (rc == NLSH_OK && hipEventRecord(s->done, last) != hipSuccess) {   // the slot starts out free
         set_error("step_create: hipEventRecord failed");
         rc = NLSH_E_HIP;
     }
@@ -114,10 +126,21 @@ extern "C" int nlsh_step_create(const nlsh_step_desc_t *desc, size_t desc_bytes,
     return NLSH_OK;
 }
 
+extern "C" int nlsh_step_create(const nlsh_step_desc_t *desc, size_t desc_bytes, nlsh_step_t **out) {
+    return step_create(desc, desc_bytes, nullptr, out);
+}
+
+extern "C" int nlsh_step_create_graph(const nlsh_step_desc_t *desc, size_t desc_bytes, nlsh_stream_t lane, nlsh_step_t **out) {
+    NLSH_REQUIRE(lane != nullptr, NLSH_E_INVALID, "step_create_graph: the slot's stream must be a real stream (not the default stream: it is captured)");
+    return step_create(desc, desc_bytes, (hipStream_t)lane, out);
+}
+
 extern "C" int nlsh_step_destroy(nlsh_step_t *s) {
     if (!s) return NLSH_OK;
     for (hipEvent_t e : {s->ready, s->encoded, s->planned, s->scanned, s->done})
         if (e) (void)hipEventDestroy(e);
+    if (s->exec) (void)hipGraphExecDestroy(s->exec);
+    if (s->graph) (void)hipGraphDestroy(s->graph);
     delete s;
     return NLSH_OK;
 }
@@ -133,10 +156,100 @@ static int scan_phase(const nlsh_step *s, const float *queries, int64_t q_stride
     return scan_call(s->d, queries, q_stride, ev0, ev1, stream, phases, plan_blocks, nullptr);
 }
 
+// A graph slot's batch: the five launches replayed from the slot's captured graph on the slot's own stream.  Batches of different slots
+// overlap because their streams do (the slot's previous batch precedes this one on the same stream: no event between them).  Per batch the
+// host makes ONE graph launch, two node updates (the encode's batch pointer / stride / seed / lookup arguments, the scan's query
+// pointer) and the `done` record -- r05's staged slots made seven launches and eight to ten event calls (~3.5 us each inside the runtime).
+// With scan events requested the batch is launched eagerly on the same stream (an event record cannot be re-pointed in a graph).
+static int graph_capture(nlsh_step *s, const float *queries, int64_t q_stride, uint64_t seed) {
+    NLSH_CHECK_HIP(hipStreamBeginCapture(s->lane, hipStreamCaptureModeThreadLocal));
+    int plan_phase, plan_blocks;
+    int rc = launch_encode(s->enc, s->d, queries, q_stride, seed, s->lane, &plan_phase, &plan_blocks);
+    if (rc == NLSH_OK) rc = scan_call(s->d, queries, q_stride, nullptr, nullptr, (nlsh_stream_t)s->lane, plan_phase | NLSH_PHASE_SCAN | NLSH_PHASE_MERGE, plan_blocks, nullptr);
+    hipGraph_t g = nullptr;
+    const hipError_t ce = hipStreamEndCapture(s->lane, &g);
+    if (rc != NLSH_OK) {
+        if (g) (void)hipGraphDestroy(g);
+        return rc;
+    }
+    NLSH_CHECK_HIP(ce);
+    s->graph = g;
+    // the two nodes whose arguments change per batch, found by their kernels
+    EncNode en;
+    ScanNode sn;
+    BucketScanCall c;
+    rc = scan_call(s->d, queries, q_stride, nullptr, nullptr, (nlsh_stream_t)s->lane, NLSH_PHASE_SCAN, 0, &c);
+    if (rc == NLSH_OK) rc = bucket_scan_node(c, &sn);
+    if (rc == NLSH_OK) rc = encode_plan_node(s->enc, queries, q_stride, seed, nullptr, &en);
+    if (rc != NLSH_OK) return rc;
+    size_t n = 0;
+    NLSH_CHECK_HIP(hipGraphGetNodes(g, nullptr, &n));
+    hipGraphNode_t nodes[16];
+    NLSH_REQUIRE(n >= 2 && n <= 16, NLSH_E_HIP, "step graph: %zu nodes captured", n);
+    NLSH_CHECK_HIP(hipGraphGetNodes(g, nodes, &n));
+    for (size_t i = 0; i < n; ++i) {
+        hipGraphNodeType t;
+        NLSH_CHECK_HIP(hipGraphNodeGetType(nodes[i], &t));
+        if (t != hipGraphNodeTypeKernel) continue;
+        hipKernelNodeParams kp;
+        NLSH_CHECK_HIP(hipGraphKernelNodeGetParams(nodes[i], &kp));
+        if (kp.func == en.p.func) s->enc_node = nodes[i];
+        else if (kp.func == sn.p.func) s->scan_node = nodes[i];
+    }
+    NLSH_REQUIRE(s->enc_node && s->scan_node, NLSH_E_HIP, "step graph: the encode / scan nodes were not found among the %zu captured", n);
+    NLSH_CHECK_HIP(hipGraphInstantiate(&s->exec, g, nullptr, nullptr, 0));
+    return NLSH_OK;
+}
+
+static int graph_enqueue(nlsh_step *s, const float *queries, int64_t q_stride, uint64_t seed, nlsh_stream_t producer, void *ev0, void *ev1) {
+    const hipStream_t lane = s->lane;
+    if ((hipStream_t)producer != lane) {    // the batch may still be in flight on the stream that produced it (as for the staged slots)
+        const hipError_t qe = hipStreamQuery((hipStream_t)producer);
+        if (qe == hipErrorNotReady) {
+            (void)hipGetLastError();
+            NLSH_CHECK_HIP(hipEventRecord(s->ready, (hipStream_t)producer));
+            NLSH_CHECK_HIP(hipStreamWaitEvent(lane, s->ready, 0));
+        } else {
+            NLSH_CHECK_HIP(qe);
+        }
+    }
+    int rc;
+    if (ev0 || ev1) {
+        int plan_phase, plan_blocks;
+        rc = launch_encode(s->enc, s->d, queries, q_stride, seed, lane, &plan_phase, &plan_blocks);
+        if (rc == NLSH_OK) rc = scan_call(s->d, queries, q_stride, ev0, ev1, (nlsh_stream_t)lane, plan_phase | NLSH_PHASE_SCAN | NLSH_PHASE_MERGE, plan_blocks, nullptr);
+        if (rc != NLSH_OK) return rc;
+    } else {
+        if (!s->exec) {
+            rc = graph_capture(s, queries, q_stride, seed);
+            if (rc != NLSH_OK) return rc;
+        }
+        // this batch's arguments of the two nodes that carry them
+        BucketScanCall c;
+        rc = scan_call(s->d, queries, q_stride, nullptr, nullptr, (nlsh_stream_t)lane, NLSH_PHASE_SCAN, 0, &c);
+        if (rc != NLSH_OK) return rc;
+        PlanArgs pa;
+        EncNode en;
+        ScanNode sn;
+        rc = bucket_scan_plan_args(c, &pa);
+        if (rc == NLSH_OK) rc = encode_plan_fuse_lookup(s->enc, pa);
+        if (rc == NLSH_OK) rc = encode_plan_node(s->enc, queries, q_stride, seed, &pa, &en);
+        if (rc == NLSH_OK) rc = bucket_scan_node(c, &sn);
+        if (rc != NLSH_OK) return rc;
+        NLSH_CHECK_HIP(hipGraphExecKernelNodeSetParams(s->exec, s->enc_node, &en.p));
+        NLSH_CHECK_HIP(hipGraphExecKernelNodeSetParams(s->exec, s->scan_node, &sn.p));
+        NLSH_CHECK_HIP(hipGraphLaunch(s->exec, lane));
+    }
+    if (s->d.hold_done) s->done_pending = true;     // the caller queues more work on the slot's stream (the shard exchange) first
+    else NLSH_CHECK_HIP(hipEventRecord(s->done, lane));
+    return NLSH_OK;
+}
+
 extern "C" int nlsh_query_step_enqueue(nlsh_step_t *s, const float *queries, int64_t q_stride, uint64_t seed, nlsh_stream_t producer,
                                        void *ev_scan_begin, void *ev_scan_end) {
     NLSH_REQUIRE(s && queries, NLSH_E_INVALID, "query_step_enqueue: null pointer");
     NLSH_REQUIRE(!s->done_pending, NLSH_E_INVALID, "query_step_enqueue: the slot's previous batch was not released (nlsh_step_release)");
+    if (s->lane) return graph_enqueue(s, queries, q_stride, seed, producer, ev_scan_begin, ev_scan_end);
     const hipStream_t front = (hipStream_t)s->d.front, mid = (hipStream_t)s->d.mid, tail = (hipStream_t)s->d.tail;
     NLSH_CHECK_HIP(hipStreamWaitEvent(front, s->done, 0));            // the slot's previous batch has left the tail: its buffers are free
     // The batch may still be in flight on the stream that produced it.  NULL is a stream like any other here -- the default stream, where
@@ -179,7 +292,7 @@ extern "C" int nlsh_query_step_enqueue(nlsh_step_t *s, const float *queries, int
 
 extern "C" int nlsh_step_release(nlsh_step_t *s) {
     NLSH_REQUIRE(s, NLSH_E_INVALID, "step_release: null pointer");
-    NLSH_CHECK_HIP(hipEventRecord(s->done, (hipStream_t)s->d.tail));
+    NLSH_CHECK_HIP(hipEventRecord(s->done, s->lane ? s->lane : (hipStream_t)s->d.tail));
     s->done_pending = false;
     return NLSH_OK;
 }

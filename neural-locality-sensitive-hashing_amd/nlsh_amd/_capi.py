@@ -28,7 +28,7 @@ SYMBOLS = (
     "nlsh_build_csr_workspace", "nlsh_build_csr", "nlsh_bucket_order_workspace", "nlsh_bucket_order", "nlsh_build_cells_workspace", "nlsh_build_cells", "nlsh_gather_rows",
     "nlsh_scan_workspace", "nlsh_scan_workspace_layout", "nlsh_scan_topk", "nlsh_scan_topk_phase", "nlsh_scan_topk_cells_phase",
     "nlsh_merge_topk",
-    "nlsh_step_create", "nlsh_step_destroy", "nlsh_step_set_weights", "nlsh_query_step_enqueue", "nlsh_step_release", "nlsh_step_busy", "nlsh_query_batch",
+    "nlsh_step_create", "nlsh_step_create_graph", "nlsh_step_destroy", "nlsh_step_set_weights", "nlsh_query_step_enqueue", "nlsh_step_release", "nlsh_step_busy", "nlsh_query_batch",
 )
 
 
@@ -118,6 +118,8 @@ def lib():
     L.nlsh_merge_topk.argtypes = [vp, i64, i32, i64, i32, vp, vp, vp, vp, vp]
     L.nlsh_step_create.restype = i32
     L.nlsh_step_create.argtypes = [ctypes.POINTER(StepDesc), sz, ctypes.POINTER(vp)]
+    L.nlsh_step_create_graph.restype = i32
+    L.nlsh_step_create_graph.argtypes = [ctypes.POINTER(StepDesc), sz, vp, ctypes.POINTER(vp)]
     for name in ("nlsh_step_destroy", "nlsh_step_release", "nlsh_step_busy"):
         getattr(L, name).restype = i32
         getattr(L, name).argtypes = [vp]

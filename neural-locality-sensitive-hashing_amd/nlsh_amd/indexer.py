@@ -348,6 +348,26 @@ class Indexer:
             got = self._cells[window_rows] = (cell_of, cell_offsets[:nc + 1], cell_order[:max(nc, 1)], nc)
         return got
 
+    # EXPERIMENT (r06, off by default): consecutive batches walk the schedule order of the cells in OPPOSITE directions behind a common
+    # prefix of the `alternate_keep` largest cells.  The order changes speed, never results.  Idea: a batch of a balanced hash touches
+    # most of the corpus (GloVe-shaped: 0.36 of 0.47 GB) in the SAME order every time, so what the 256-MiB Infinity Cache holds at the
+    # end of batch i -- the rows of the schedule's tail -- is what batch i+1 needs last; walked backwards it needs them first.
+    alternate_order = False
+    alternate_keep = 0
+
+    def _order_for_this_batch(self, window, cell_order, nc):
+        if not self.alternate_order or nc < 2:
+            return cell_order
+        self._order_phase = getattr(self, "_order_phase", 0) ^ 1
+        if not self._order_phase:
+            return cell_order
+        rev = self.__dict__.setdefault("_cell_order_rev", {}).get((window, self.alternate_keep))
+        if rev is None:
+            keep = min(max(int(self.alternate_keep), 0), nc)
+            rev = torch.cat([cell_order[:keep], cell_order[keep:nc].flip(0)]).contiguous()
+            self._cell_order_rev[(window, self.alternate_keep)] = rev
+        return rev
+
     def choose_window(self, Q, P, algo):
         """Row window of the small-bucket packing for one batch shape (tiled schedule only): 64 rows unless forced.
         Measured (r04, tools/scan_bench.py --window 0,64,128,256 --rounds 4, same process and keys, scan kernel ms, one box):
@@ -474,7 +494,7 @@ class Indexer:
             window = self.choose_window(Q, keys.shape[1], algo)
         if window and algo == _capi.SCAN_BUCKET_TILED:
             cell_of, cell_offsets, cell_order, nc = self.cells(window)
-            sched = (a(cell_order), self.n_buckets, a(cell_of), a(cell_offsets), nc)
+            sched = (a(self._order_for_this_batch(window, cell_order, nc)), self.n_buckets, a(cell_of), a(cell_offsets), nc)
         else:
             sched = (a(self.bucket_order), self.n_buckets, None, None, 0)
         pre = (a(self.corpus_sorted), self.row_stride, d, a(self.gid), a(self.uniq_keys), a(self.offsets), *sched, a(self.inv_norm))

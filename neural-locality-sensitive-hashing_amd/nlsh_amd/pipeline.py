@@ -44,11 +44,17 @@ class _Slot:
 
 class QueryPipeline:
 
+    default_graph = True     # slots replay a captured hipGraph of the batch on a stream of their own (False: the staged streams of r03-r05)
+
     def __init__(self, indexer, sample_queries, k=10, hash_times=10, depth=3, want_keys=False,
-                 exchange: Optional[Callable] = None, split_front: Optional[bool] = None):
+                 exchange: Optional[Callable] = None, split_front: Optional[bool] = None, graph: Optional[bool] = None):
         """`sample_queries`: a batch of the shape every later batch has (sizes the task table with one ordinary,
         checked call).  `exchange(keys64, ncand) -> (dist, idx, ncand)`: the sharded index's all-gather + merge,
-        run on the tail stream (needs the 64-bit keys, so it implies want_keys)."""
+        run on the tail stream (needs the 64-bit keys, so it implies want_keys).
+        `graph` (r06, ABI v4): True = every slot replays a captured hipGraph of the batch's five launches on a stream of its OWN
+        (`nlsh_step_create_graph`): batches overlap because the slots' streams do, and a submit costs the host one graph launch + two
+        node updates instead of the staged slots' five launches + eight to ten event calls.  False = the three / four stage streams of
+        r03-r05.  None = graph slots whenever the schedule is a bucket-major one (`QueryPipeline.default_graph`)."""
         if hash_times > _capi.MAX_PROBES:
             raise _capi.NlshHipError(_capi.E_UNSUPPORTED, f"pipelined batches take hash_times <= {_capi.MAX_PROBES}")
         if depth < 2:
@@ -61,6 +67,11 @@ class QueryPipeline:
         self.Q, self.d = q.shape
         indexer.query_tensors(q, k=k, hash_times=hash_times, seed=0, check=True)     # sizes indexer._max_tasks
         torch.cuda.synchronize(dev)
+        if graph is None:
+            graph = self.default_graph
+        self.graph = bool(graph) and indexer.last_algo != _capi.SCAN_QUERY_MAJOR and indexer.n_buckets > 0
+        if self.graph:
+            split_front = False
         if split_front is None:
             # Four stages (the PLAN phase on a stream of its own behind the encode) pay when the front stage -- encode + PLAN, two
             # latency-bound chains of ~40 us each whatever the shard size -- is about as long as the scan: small shards of a
@@ -95,6 +106,7 @@ class QueryPipeline:
         self.slots = []
         for _ in range(depth):
             s = _Slot()
+            s.lane = torch.cuda.Stream(device=dev) if self.graph else None    # graph slots: one stream per slot
             s.keys = torch.empty((self.Q, self.P), dtype=torch.int32, device=dev)
             s.nkeys = torch.empty((self.Q,), dtype=torch.int32, device=dev)
             s.out_dist = torch.empty((self.Q, k), dtype=torch.float32, device=dev)
@@ -135,14 +147,18 @@ class QueryPipeline:
             front=self.front.cuda_stream, plan=self.plan.cuda_stream if self.plan is not None else None, mid=self.mid.cuda_stream,
             tail=self.tail.cuda_stream)
         handle = ctypes.c_void_p()
-        _capi.check(self._lib.nlsh_step_create(ctypes.byref(desc), ctypes.sizeof(desc), ctypes.byref(handle)))
+        if self.graph:
+            _capi.check(self._lib.nlsh_step_create_graph(ctypes.byref(desc), ctypes.sizeof(desc), s.lane.cuda_stream, ctypes.byref(handle)))
+        else:
+            _capi.check(self._lib.nlsh_step_create(ctypes.byref(desc), ctypes.sizeof(desc), ctypes.byref(handle)))
         return handle
 
     def _bind_weights(self):
         """Point every slot at the hasher's CURRENT packed weights and keep the blob alive for as long as the slots point at it."""
         h = self.indexer._hashing
         packed = h.packed_weights()
-        packed.record_stream(self.front)      # read by encode_hash on the front stream, allocated on the caller's
+        for st in ([sl.lane for sl in self.slots] if self.graph else [self.front]):
+            packed.record_stream(st)          # read by encode_hash on the front stream (the slots' lanes), allocated on the caller's
         self._weights_sig = h._weights_signature()
         for s in self.slots:
             if s.step is None:
@@ -155,7 +171,7 @@ class QueryPipeline:
     def close(self):
         """Destroy the slots' library objects (after the batches in flight have finished)."""
         if getattr(self, "slots", None):
-            self.tail.synchronize()
+            self.synchronize()
             for s in self.slots:
                 if s.step is not None:
                     self._lib.nlsh_step_destroy(s.step)
@@ -167,7 +183,9 @@ class QueryPipeline:
         except Exception:      # interpreter shutdown: the process is going away with the handles
             pass
 
-    def _stage_streams(self):
+    def _stage_streams(self, slot=None):
+        if self.graph:
+            return (slot.lane,) if slot is not None else tuple(sl.lane for sl in self.slots)
         return (self.front, self.mid, self.tail) + ((self.plan,) if self.plan is not None else ())
 
     def submit(self, queries, seed=None, events=None):
@@ -189,13 +207,14 @@ class QueryPipeline:
         self.n_submitted += 1
         if ix._hashing._weights_signature() != self._weights_sig:
             if self.n_submitted > 1:
-                torch.cuda.current_stream(queries.device).wait_stream(self.front)   # batches in flight still read the old blob
+                for st in ([sl.lane for sl in self.slots] if self.graph else [self.front]):
+                    torch.cuda.current_stream(queries.device).wait_stream(st)       # batches in flight still read the old blob
             self._bind_weights()
         if s.batch is not None and s.batch is not queries and L.nlsh_step_busy(s.step) != 0:
             # the slot's previous batch is still in flight and its tensor is about to lose our reference: keep its memory away from
             # the allocator until the stage streams have passed it (the host runs a pipeline depth ahead: the device-bound regime,
             # where these calls cost nothing that matters)
-            for st in self._stage_streams():
+            for st in self._stage_streams(s):
                 s.batch.record_stream(st)
         if seed is None:
             seed = ix._hashing.next_seed()
@@ -205,14 +224,18 @@ class QueryPipeline:
         _capi.check(rc)
         out = (s.out_dist, s.out_idx, s.ncand, s.out_keys)
         if self.exchange is not None:
-            with torch.cuda.stream(self.tail):
+            with torch.cuda.stream(s.lane if self.graph else self.tail):
                 out = tuple(self.exchange(s.out_keys, s.ncand)) + (None,)
             _capi.check(L.nlsh_step_release(s.step))
         self.last_slot = s
         return out
 
     def synchronize(self):
-        self.tail.synchronize()
+        if self.graph:
+            for s in self.slots:
+                s.lane.synchronize()
+        else:
+            self.tail.synchronize()
 
     def overflowed(self) -> bool:
         """True if any slot's last batch did not fit the task table (results incomplete: rebuild the pipeline).

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--pipeline", action="store_true", help="three-stage pipeline over three streams (nlsh_amd/pipeline.py)")
     ap.add_argument("--split-front", default="auto", choices=["auto", "on", "off"], help="with --pipeline: the PLAN phase on a stream of its own (four stages); auto = the pipeline's own choice")
     ap.add_argument("--depth", type=int, default=3)
+    ap.add_argument("--graph-events", action="store_true", help="graph slots: pass scan events anyway (the batch is then launched eagerly on the slot's stream)")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"], help="with --pipeline: graph slots (one captured hipGraph per slot on its own stream) or the staged streams of r03-r05")
     args = ap.parse_args()
     from nlsh_amd import io, synth
     from nlsh_amd.data import SIFT
@@ -63,21 +65,22 @@ def main():
     pipe = None
     if args.pipeline:
         from nlsh_amd.pipeline import QueryPipeline
-        pipe = QueryPipeline(indexer, queries, k=10, hash_times=10, depth=args.depth, want_keys=True, split_front={"auto": None, "on": True, "off": False}[args.split_front])
+        pipe = QueryPipeline(indexer, queries, k=10, hash_times=10, depth=args.depth, want_keys=True, split_front={"auto": None, "on": True, "off": False}[args.split_front],
+                             graph={"auto": None, "on": True, "off": False}[args.graph])
         for i in range(3):
             pipe.submit(queries, seed=50 + i)
         torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         if pipe is not None:
-            pipe.submit(queries, seed=100 + i, events=ev[i])
+            pipe.submit(queries, seed=100 + i, events=None if (pipe.graph and not args.graph_events) else ev[i])   # graph slots launch a batch eagerly when its scan is to be bracketed by events
         else:
             indexer.query_tensors(queries, k=10, hash_times=10, seed=100 + i, want_keys=True, check=False, events=ev[i])
     enqueue_ms = 1e3 * (time.perf_counter() - t0) / args.steps      # host time to enqueue a step (the GPU runs behind)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    print(json.dumps({"world": args.world, "rank": args.rank, "shard": args.shard, "pipeline": bool(args.pipeline), "split_front": (pipe.split_front if pipe is not None else None), "depth": args.depth, "rows": hi - lo, "algo": indexer.last_algo,
-                      "local_step_ms": 1e3 * el / args.steps, "host_enqueue_ms": enqueue_ms, "scan_ms": float(np.mean([a.elapsed_time(b) for a, b in ev]))}))
+    print(json.dumps({"world": args.world, "rank": args.rank, "shard": args.shard, "pipeline": bool(args.pipeline), "split_front": (pipe.split_front if pipe is not None else None), "graph_slots": (pipe.graph if pipe is not None else None), "depth": args.depth, "rows": hi - lo, "algo": indexer.last_algo,
+                      "local_step_ms": 1e3 * el / args.steps, "host_enqueue_ms": enqueue_ms, "scan_ms": None if (pipe is not None and pipe.graph and not args.graph_events) else float(np.mean([a.elapsed_time(b) for a, b in ev]))}))
 
 
 if __name__ == "__main__":
