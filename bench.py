@@ -509,11 +509,11 @@ def main():
         from nlsh_amd.pipeline import QueryPipeline
         pipe = QueryPipeline(indexer, qb[0], k=k, hash_times=P, depth=3, exchange=exchange if world > 1 else None)
 
-    def device_step(i, events=None):
+    def device_step(i, events=None, mark=False):
         q = qb[i % B]
         seed = 1000 + i  # identical on every rank -> identical multi-probe keys
         if pipe is not None:
-            cur[0] = i if events is not None else None
+            cur[0] = i if (events is not None or mark) else None     # timed steps bracket their exchange with ev_x[i]
             return pipe.submit(q, seed=seed, events=events)[:3]
         dist_, idx_, nc_, k64 = indexer.query_tensors(q, k=k, hash_times=P, seed=seed, want_keys=world > 1, check=False, events=events)
         if world > 1:
@@ -533,7 +533,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     for i in range(steps):
-        device_step(i, events=None if graph_slots else ev[i])
+        device_step(i, events=None if graph_slots else ev[i], mark=True)
     if pipe is not None:
         pipe.synchronize()
     fence()

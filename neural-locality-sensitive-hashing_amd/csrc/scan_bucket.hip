@@ -1247,10 +1247,12 @@ __device__ __forceinline__ void tiled_task_body(const BArgs &a, float4 *tile, lo
         o[0] = (float)(ts4 - ts_entry); o[1] = FAST ? (float)(ts_in - ts_entry) : (float)(ts1 - ts0); o[2] = FAST ? (float)trl[0] : (float)ts_stage;
         o[3] = FAST ? (float)trl[2] : (float)ts_comp;
         o[4] = FAST ? (float)trl[1] : 0.f; o[5] = (float)(ts4 - ts3); o[6] = (float)(nq * 1000 + nrows); o[7] = (float)(ts_entry & 0xFFFFFFull);
+#ifdef NLSH_SCAN_TRACE_HWID   // (r05's placement analysis: overwrites the barrier-1 and compute columns)
         // where it ran: HW_ID (wave/simd/cu/sh/se) and XCC_ID, as exact small integers
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
         o[2] = (float)(((xcc & 0xF) << 12) | (((hw >> 13) & 0x7) << 9) | (((hw >> 12) & 0x1) << 8) | (((hw >> 8) & 0xF) << 4) | (((hw >> 4) & 0x3) << 2));
         o[3] = (float)(hw & 0xF);
+#endif
 #ifdef NLSH_SCAN_TRACE_CLOCK
         o[4] = (float)(__builtin_amdgcn_s_memtime() - core0); o[1] = (float)(ts4 - ts0);   // core cycles and 100 MHz ticks of the same interval
 #endif
