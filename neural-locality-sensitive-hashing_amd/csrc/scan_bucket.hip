@@ -1291,6 +1291,10 @@ __global__ __launch_bounds__(64 * NW, NLSH_TILED_MIN_WAVES) void bscan3_kernel(B
     // requested with the descriptor.  A wave picks its own slots out of it with v_readlane (r04: four 8-byte loads per wave), and the
     // hull of the rows the task's queries own at all is taken over all sixteen (r05).  Slots >= nq hold garbage, never used.
     const int2 qr_all = a.task_qr[tc * (QW * NW) + (lane & (QW * NW - 1))];
+    // (r06: cross-task prefetch into the XCD's L2 -- a finished workgroup touching the rows of the task 1792-3072 ids ahead on its XCD with
+    // loads nobody waits for -- was built and is NOT here: every run of it ended in a GPU exception (a wave may not end with its loads in
+    // flight on this part), and with the wait in front of s_endpgm the workgroup's slot is held for exactly the HBM miss the prefetch was
+    // meant to hide.  DESIGN.md appendix A.)
     if (t >= ntasks) return;
     if (NLSH_ABLATE == 9) return;   // diagnostic: every workgroup leaves after its descriptor loads (what dispatching the grid costs)
     if (NLSH_ABLATE == 8 && desc.y <= NLSH_ABLATE_NQ) return;   // diagnostic: tasks with few queries vanish (what the low-density tasks cost)

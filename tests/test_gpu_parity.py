@@ -521,8 +521,9 @@ def test_pipelined_batches_are_bit_identical_to_sequential_calls():
         batches = [dev(gen(Q, d, seed=50 + i)) for i in range(5)]
         want = [indexer.query_tensors(b, k=k, hash_times=P, seed=900 + i, want_keys=True) for i, b in enumerate(batches)]
         want = [tuple(t.clone() for t in w) for w in want]
-        for depth in (2, 3):
-            pipe = QueryPipeline(indexer, batches[0], k=k, hash_times=P, depth=depth, want_keys=True)
+        for depth, graph in ((2, False), (3, False), (2, True), (3, True)):    # staged streams (r03-r05) and graph slots (r06), either depth
+            pipe = QueryPipeline(indexer, batches[0], k=k, hash_times=P, depth=depth, want_keys=True, graph=graph)
+            assert pipe.graph == (graph and algo != "query")      # graph slots exist for the bucket-major schedules
             got = []
             for i, b in enumerate(batches):
                 got.append(pipe.submit(b, seed=900 + i))
@@ -530,5 +531,51 @@ def test_pipelined_batches_are_bit_identical_to_sequential_calls():
                     pipe.synchronize()
                     for j in range(i + 1 - ((i % depth) + 1), i + 1):
                         for a, w in zip(got[j], want[j]):
-                            assert torch.equal(a, w), (metric, algo, depth, j)
+                            assert torch.equal(a, w), (metric, algo, depth, graph, j)
             assert not pipe.overflowed()
+            pipe.close()
+
+
+@pytest.mark.parametrize("metric,d,algo", [("l2", 128, "tiled"), ("cosine", 100, "tiled"), ("l2", 72, "tiled"), ("l2", 128, "bucket"), ("cosine", 100, "bucket")])
+def test_one_call_batch_equals_hash_then_scan(metric, d, algo):
+    """ABI v4, `nlsh_query_batch` (what `Indexer.query_tensors` issues): encode_hash with the bucket lookup in its EPILOGUE + the rest
+    of the PLAN phase + scan + merge -- five launches -- against the separate calls (`hash_device`, then `scan_tensors`, whose PLAN phase
+    looks the caller-supplied key table up with the stand-alone kernel): key tables, key counts, ids, distance BITS, candidate counts and
+    64-bit sort keys identical, at batch sizes on both sides of every encoder form (16-row, 32-row, the 32 + 16-row launch), with and
+    without the reference's single-probe tail (F6), and for a row RANGE of a batch (row0, the range's share of the multi-probe rows).
+    The key table itself is the oracle's (Philox sampler, first-occurrence order)."""
+    from nlsh_amd.data import Glove, SIFT
+    from nlsh_amd.indexer import Indexer
+    gen = synth.sift_like if metric == "l2" else synth.glove_like
+    N, H, k = 60000, 11, 10
+    corpus = gen(N, d, seed=61)
+    Ws, bs = synth.make_weights([d, 64, 64, H], seed=61)
+    for compat in (True, False):
+        hashing = make_hashing(d, (64, 64), H, Ws, bs, compat=compat)
+        indexer = Indexer(hashing, dev(corpus), SIFT.distance if metric == "l2" else Glove.distance, compat=compat, algo=algo)
+        for Q, P in ((1, 1), (100, 10), (4097, 10), (8193, 10), (9000, 3), (12288, 10), (333, 64)):
+            q = dev(gen(Q, d, seed=70 + Q))
+            keys, nkeys = indexer.hash_device(q, hash_times=P, seed=4000 + Q)
+            want = indexer.scan_tensors(q, keys, nkeys, k=k, want_keys=True)
+            got = indexer._batch_tensors(q, k, P, 4000 + Q, want_keys=True)
+            assert indexer._fuses(q, P, indexer.last_algo)
+            assert torch.equal(got[4], keys) and torch.equal(got[5], nkeys), (compat, Q, P)
+            for a, w in zip(got[:4], want):
+                assert torch.equal(a, w), (compat, Q, P)
+            if Q in (100, 8193):     # the key table against the oracle's sampler
+                _, probs, _ = hashing.forward_device(q)
+                ko, no = oracle.row_keys(probs.cpu().numpy(), P, "ref_int16" if compat else "full", seed=4000 + Q, n_multi_rows=indexer._n_multi_rows(Q))
+                kd = keys.cpu().numpy().astype(np.int64) & (0xFFFFFFFF if not compat else -1)
+                live = np.arange(P)[None, :] < no[:, None]
+                assert np.array_equal(nkeys.cpu().numpy(), no) and np.array_equal(kd[live], (ko if compat else ko & 0xFFFFFFFF)[live])
+        # a row range of a larger batch: hashed and scanned by one call into its slice of the batch's key table
+        Q, P, lo, hi = 9000, 10, 4000, 8500
+        q = dev(gen(Q, d, seed=99))
+        keys, nkeys = indexer.hash_device(q, hash_times=P, seed=77)
+        want = indexer.scan_tensors(q[lo:hi], keys[lo:hi].contiguous(), nkeys[lo:hi].contiguous(), k=k, want_keys=True)
+        tab, cnt = torch.zeros_like(keys), torch.zeros_like(nkeys)
+        n_multi = indexer._n_multi_rows(Q)
+        got = indexer._batch_tensors(q[lo:hi], k, P, 77, want_keys=True, row0=lo, n_multi=min(max(n_multi - lo, 0), hi - lo), out=(tab[lo:hi], cnt[lo:hi]))
+        assert torch.equal(tab[lo:hi], keys[lo:hi]) and torch.equal(cnt[lo:hi], nkeys[lo:hi])
+        for a, w in zip(got[:4], want):
+            assert torch.equal(a, w), (compat, "range")

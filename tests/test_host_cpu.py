@@ -437,6 +437,40 @@ def test_promote_results_still_promotes_through_a_paused_query(monkeypatch):
     assert Indexer._promotions == before + 2
 
 
+def test_step_create_refuses_equal_streams_and_bad_scan_arguments_before_anything_is_enqueued():
+    """ADVICE r05 / VERDICT r05 item 5: `nlsh_step_create` used to check that front, mid and tail were non-NULL, not that they differ, and
+    the scan call's own argument checks (workspace alignment, strides) only ran inside the first enqueue, behind its encode.  Both are
+    refused by the constructor now -- on the host, before any HIP call, so this runs without a GPU."""
+    import ctypes
+    from nlsh_amd import _capi
+    L = _capi.lib()
+    dims = _capi.int_array([128, 64, 16])
+    buf = (ctypes.c_char * 4096)()
+    a = ctypes.addressof(buf)
+    def desc(**kw):
+        base = dict(n_layers=2, act=0, key_mode=0, n_probes=10, dims=ctypes.cast(dims, ctypes.c_void_p), packed=a, n_multi_rows=0,
+                    corpus_sorted=a, row_stride=128, gid=a, uniq_keys=a, offsets=a, bucket_order=a, cell_of=None, cell_offsets=None, inv_norm=None,
+                    d=128, n_buckets=8, n_cells=0, k=10, metric=0, algo=2, seg_rows=0, hold_done=0, Q=64, qkeys=a, nkeys=a, out_dist=a, out_idx=a,
+                    out_keys=None, out_ncand=a, status=a, workspace=a, workspace_bytes=4096, max_tasks=16, front=0x1000, plan=None, mid=0x2000, tail=0x3000)
+        base.update(kw)
+        return _capi.StepDesc(**base)
+    handle = ctypes.c_void_p()
+    for bad in (dict(mid=0x1000), dict(tail=0x2000), dict(tail=0x1000), dict(plan=0x3000), dict(front=None)):
+        d_ = desc(**bad)
+        rc = L.nlsh_step_create(ctypes.byref(d_), ctypes.sizeof(d_), ctypes.byref(handle))
+        assert rc == _capi.E_INVALID and not handle.value, bad
+        assert b"stream" in L.nlsh_last_error()
+    # distinct streams, but a scan argument the scan call itself refuses: a workspace that is not 16-byte aligned / too small
+    for bad, word in ((dict(workspace=a + 4), b"aligned"), (dict(workspace_bytes=64), b"workspace"), (dict(row_stride=126), b"row_stride")):
+        d_ = desc(**bad)
+        rc = L.nlsh_step_create(ctypes.byref(d_), ctypes.sizeof(d_), ctypes.byref(handle))
+        assert rc in (_capi.E_INVALID, _capi.E_WORKSPACE) and not handle.value, bad
+        assert word in L.nlsh_last_error(), (bad, L.nlsh_last_error())
+    # graph slots: the slot's stream must be a real one
+    d_ = desc()
+    assert L.nlsh_step_create_graph(ctypes.byref(d_), ctypes.sizeof(d_), None, ctypes.byref(handle)) == _capi.E_INVALID
+
+
 def test_fastlists_builds_the_same_lists_as_ndarray_tolist():
     """csrc/fastlists.c: the host-side list builder of `Indexer._plain_lists` is `ndarray.tolist()` element for element (types too),
     refuses a short buffer, and is what the facade uses when it is built."""

@@ -137,7 +137,7 @@ def main():
         torch.cuda.synchronize()
         step_ms = 1e3 * (time.perf_counter() - t0) / args.iters
         dist, idx, nc, _ = out
-        rec = {"tag": args.tag, "l2_form": args.l2_form, "lib": os.path.basename(os.environ.get("NLSH_HIP_LIB", "default")), "algo": args.algo,
+        rec = {"tag": args.tag, "workload": args.workload, "l2_form": args.l2_form, "lib": os.path.basename(os.environ.get("NLSH_HIP_LIB", "default")), "algo": args.algo,
                "scan_kernel_ms": float(kern.mean()), "scan_kernel_ms_min": float(kern.min()), "scan_phases_ms": scan_call_ms,
                "step_ms": step_ms, "tasks": int(ix.last_status.cpu()[0]), "max_tasks": ix._last_max_tasks, "sum_candidates": int(nc.long().sum())}
         if os.environ.get("SCAN_BENCH_GROUPS"):   # pairs by the size of the query group they sit in (host recomputation from the keys)
