@@ -244,6 +244,16 @@ __global__ __launch_bounds__(256) void bscan_kernel(BArgs a, int plan_blocks) {
     __shared__ int neg_s, flags_s;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (threadIdx.x == 0) { neg_s = 0; flags_s = 0; }
+    const bool last_block = blockIdx.x == gridDim.x - 1;
+    // the last block's verdict needs the lookup's per-block pair counts: requested NOW, with the first loads of the kernel, not behind the
+    // look-back (the last block ends the kernel: a round trip on its path is a round trip of the launch)
+    int hsum = 0, hflags = 0;
+    if (last_block)
+        for (int j = threadIdx.x; j < plan_blocks; j += 256) {
+            const int h = a.hits[j];
+            hsum += h & PLAN_HITS_MASK;
+            hflags |= h & ~PLAN_HITS_MASK;
+        }
     int b = 0, m = 0, s = 0, ns = 0, ng = 0;
     bool neg = false;
     if (i < a.nc) {
@@ -277,14 +287,7 @@ __global__ __launch_bounds__(256) void bscan_kernel(BArgs a, int plan_blocks) {
         if (threadIdx.x == 0) base_s = ptot;
         if (pneg) neg_s = 1;
     }
-    const bool last_block = blockIdx.x == gridDim.x - 1;
     if (last_block) {   // the verdict: every total is known here
-        int hsum = 0, hflags = 0;
-        for (int j = threadIdx.x; j < plan_blocks; j += 256) {
-            const int h = a.hits[j];
-            hsum += h & PLAN_HITS_MASK;
-            hflags |= h & ~PLAN_HITS_MASK;
-        }
         unsigned long long htot;
         __syncthreads();
         block_excl_scan64((unsigned long long)(unsigned)hsum, wsum, &htot);
@@ -942,7 +945,7 @@ __device__ __forceinline__ void l2_task_nt(int ntile, float4 *tile, const float4
 }
 
 // Merge of ONE query's partial lists into its final top-k (one wavefront; `sc` = 64 u64 of LDS scratch owned by the wave).
-__device__ __forceinline__ void merge_query(const BArgs &a, long long q, int lane, uint64_t *sc) {
+__device__ __forceinline__ void merge_query(const BArgs &a, long long q, int lane, uint64_t *sc, int2 *ltab) {
     // lane p holds probe p's record (written by bscatter): where its partial lists are.  bscatter writes a record for EVERY slot of
     // the [Q, P] table -- zeros for slots past the query's key count, for repeated keys and for keys without a bucket -- so the key
     // count is not needed here (r04: its load sat in front of the record load, one dependent round trip per wave)
@@ -955,36 +958,46 @@ __device__ __forceinline__ void merge_query(const BArgs &a, long long q, int lan
         ns_l = (size_l + a.seg - 1) / a.seg;
     }
     {   // n_candidates of the query (indexer.py:71,94) = rows of its probed buckets
-        int c = size_l;
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m);
+        const int c = __builtin_amdgcn_readlane(wave_incl_scan_i32(size_l), 63);
         if (lane == 0) a.out_ncand[q] = c;
     }
     // The query's partial lists (one per probe and row segment) are numbered 0..L-1 by an inclusive scan of the
     // per-probe segment counts.  A round fetches 3 x R lists (R = 64/k per load instruction: lane -> (list, entry)) and
     // SELECTS the k best of them and the best so far (merge_round); typical queries (<= 18 lists at k = 10) take one round.
-    int incl = ns_l;
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const int up = __shfl_up(incl, m);
-        if (lane >= m) incl += up;
-    }
+    const int incl = wave_incl_scan_i32(ns_l);
     const int L = __builtin_amdgcn_readlane(incl, 63);
     const int R = 64 / a.k;
     const int r = lane / a.k, e = lane - r * a.k;
+    // r06: where list `li` lives -- (task, slot) -- comes from a table in LDS that lane p fills for its probe's ns_l lists (task of
+    // segment si = first task + si * query groups), instead of a 6-step shuffle search + 6 more shuffles per fetched list: the merge is
+    // bound by its instruction count (10^4 waves x ~10 per SIMD), and a typical query has 5-18 lists of 1-2 segments per probe.  Queries
+    // with a probe of more than LIST_TAB_MAX_SEG segments (a giant bucket) or more than LIST_TAB lists keep the search.
+    constexpr int LIST_TAB = 128, LIST_TAB_MAX_SEG = 8;
+    const bool tabbed = ltab != nullptr && L <= LIST_TAB && (int)wave_minmax_u32<true>((uint32_t)ns_l) <= LIST_TAB_MAX_SEG;   // wave-uniform
+    if (tabbed) {
+        const int first = incl - ns_l;
+        for (int si = 0; si < LIST_TAB_MAX_SEG; ++si)
+            if (si < ns_l) ltab[first + si] = make_int2((int)(t0_l + (long long)si * ng_l), j_l);
+    }
     // keys of list slot `li` (one list per group of k lanes): which probe it belongs to, which segment of that probe's bucket
     auto fetch = [&](int li) -> uint64_t {
-        int lo = 0, hi = 63;  // probe of list li = first lane whose inclusive count exceeds li
+        long long t;
+        int j;
+        if (tabbed) {
+            const int2 ent = ltab[(r < R && li < L) ? li : 0];   // same wave wrote it: LDS operations of a wave complete in order
+            t = ent.x; j = ent.y;
+        } else {
+            int lo = 0, hi = 63;  // probe of list li = first lane whose inclusive count exceeds li
 #pragma unroll
-        for (int step = 0; step < 6; ++step) {
-            const int mid = (lo + hi) >> 1;
-            if (__shfl(incl, mid) > li) hi = mid; else lo = mid + 1;
+            for (int step = 0; step < 6; ++step) {
+                const int mid = (lo + hi) >> 1;
+                if (__shfl(incl, mid) > li) hi = mid; else lo = mid + 1;
+            }
+            const int p = lo > 63 ? 63 : lo;
+            const int si = li - (__shfl(incl, p) - __shfl(ns_l, p));
+            t = (long long)(((unsigned long long)(unsigned)__shfl((int)(t0_l >> 32), p) << 32) | (unsigned)__shfl((int)t0_l, p)) + (long long)si * __shfl(ng_l, p);
+            j = __shfl(j_l, p);
         }
-        const int p = lo > 63 ? 63 : lo;
-        const int si = li - (__shfl(incl, p) - __shfl(ns_l, p));
-        const long long t = (long long)(((unsigned long long)(unsigned)__shfl((int)(t0_l >> 32), p) << 32) | (unsigned)__shfl((int)t0_l, p)) +
-                            (long long)si * __shfl(ng_l, p);
-        const int j = __shfl(j_l, p);
         // t >= max_tasks: table overflow, status[1] was set by the scan kernel and the caller repeats the call
         const bool live = r < R && li < L && t < a.max_tasks;
         const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.partial) + ((live ? t : 0) * a.QB + j) * a.k + e;
@@ -1308,7 +1321,8 @@ __global__ __launch_bounds__(256) void bmerge_kernel(BArgs a) {
     const int lane = threadIdx.x & 63;
     const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     __shared__ uint64_t scratch[4][64];
-    if (q < a.Q) merge_query(a, q, lane, scratch[threadIdx.x >> 6]);
+    __shared__ int2 list_tab[4][128];    // merge_query's LIST_TAB entries per wave
+    if (q < a.Q) merge_query(a, q, lane, scratch[threadIdx.x >> 6], list_tab[threadIdx.x >> 6]);
 }
 
 #ifndef NLSH_TILED_QB

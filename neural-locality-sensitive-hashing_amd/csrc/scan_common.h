@@ -126,6 +126,18 @@ __device__ __forceinline__ uint32_t wave_minmax_u32(uint32_t x) {
     return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
 }
 
+// wave-wide inclusive prefix sum of an i32 (lane l gets x_0 + ... + x_l): four row_shr steps inside each 16-lane row (zero fill), then the
+// row totals carried across with row_bcast15 / row_bcast31 -- six DPP adds, no LDS crossbar (`__shfl_up` is a ds_bpermute per step)
+__device__ __forceinline__ int wave_incl_scan_i32(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);    // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);    // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);    // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);    // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast15: lane 15 of rows 0 / 2 into rows 1 / 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast31: lane 31 into rows 2 and 3
+    return x;
+}
+
 // k smallest of the wave's NK*64 keys (NK per lane, KEY_NONE = absent), written UNSORTED to out[0..k)
 // (KEY_NONE padded), without any ordered insertion.  A bisection on the distance word looks for ANY threshold that
 // separates exactly k keys (ballots + scalar popcounts): it starts from the [min, max] bracket of the present

@@ -22,7 +22,10 @@ if [ "${1:-main}" = "main" ]; then
   python bench.py --data clusters --no-cpu-baseline > $O/bench_clusters.json 2>/dev/null
   python bench.py --workload glove --no-cpu-baseline > $O/bench_glove.json 2>/dev/null
   python bench.py --workload glove --no-cpu-baseline --algo query > $O/bench_glove_query_major.json 2>/dev/null
-  for w in 1 2 4 8; do python tools/shard_step_profile.py --world $w --rank 0 --steps 50; done 2>/dev/null > $O/shard_step_profile.jsonl
+  for w in 1 2 4 8; do python tools/shard_step_profile.py --world $w --rank 0 --steps 50; done 2>/dev/null > $O/shard_step_profile_sequential.jsonl
+  for g in on off; do for w in 1 2 4 8; do python tools/shard_step_profile.py --world $w --rank 0 --steps 100 --pipeline --graph $g; done; done 2>/dev/null > $O/shard_step_profile_pipelined.jsonl
+  python tools/graph_enqueue_probe.py 2>/dev/null > $O/graph_enqueue_probe.json
+  for w in glove clusters sift1m; do python tools/order_alternation.py $w 2>/dev/null; done > $O/order_alternation_and_cache_flush.jsonl
   CLK=""
   if [ -f $R/neural-locality-sensitive-hashing_amd/lib/libnlsh_hip_trace.so ]; then
     NLSH_HIP_LIB=$R/neural-locality-sensitive-hashing_amd/lib/libnlsh_hip_trace.so python tools/scan_clock.py > $O/scan_clock.txt 2>/dev/null || true
@@ -32,8 +35,12 @@ if [ "${1:-main}" = "main" ]; then
   rm -rf /tmp/kt && (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --no-cpu-baseline --no-side-workloads --query-chunks 1 > $O/bench_under_rocprof.json 2> /tmp/kt.err)
   cp $(find /tmp/kt -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
   python3 $R/tools/kernel_trace_regions.py /tmp/kt > $O/kernel_trace_regions.txt
-  rm -rf /tmp/kts && (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --output-format csv -d /tmp/kts -- python3 $R/tools/step_timeline.py > /dev/null 2> /tmp/kts.err)
-  python3 $R/tools/step_timeline.py --parse /tmp/kts > $O/step_timeline.txt 2>/dev/null || true
+  : > $O/step_timeline.txt
+  for wl in sift1m clusters glove; do
+    rm -rf /tmp/kts && (cd /tmp && STEP_WORKLOAD=$wl TMPDIR=/tmp rocprofv3 --kernel-trace --output-format csv -d /tmp/kts -- python3 $R/tools/step_timeline.py > /dev/null 2> /tmp/kts.err)
+    echo "== $wl (sequential device step, one nlsh_query_batch call per batch)" >> $O/step_timeline.txt
+    python3 $R/tools/step_timeline.py --parse /tmp/kts >> $O/step_timeline.txt 2>/dev/null || true
+  done
   for wl in glove clusters; do
     flags="--workload glove"; [ $wl = clusters ] && flags="--data clusters"
     rm -rf /tmp/kt_$wl && (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$wl -- python3 $R/bench.py --no-cpu-baseline --query-chunks 1 $flags > $O/bench_${wl}_under_rocprof.json 2> /tmp/kt_$wl.err)
@@ -43,6 +50,10 @@ if [ "${1:-main}" = "main" ]; then
   pmc_bench sift1m_folded --l2-form folded
   pmc_bench clusters --data clusters
   pmc_bench glove --workload glove
+  # what the L2's fabric-side read requests of the GloVe launch are made of: all of them, those routed to local DRAM (as opposed to
+  # GMI / IO -- NOT "missed the Infinity Cache": no counter of this rocprofv3 sits behind the MALL), the 32-byte ones
+  rm -rf /tmp/pm_ea && (cd /tmp && TMPDIR=/tmp rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d /tmp/pm_ea -- python3 $R/bench.py --no-cpu-baseline --no-side-workloads --steps 3 --warmup 1 --query-chunks 1 --workload glove > /dev/null 2> /tmp/pm_ea.err) || true
+  python3 $R/tools/pmc_summary.py /tmp/pm_ea bscan3 > $O/pmc_glove_ea_requests.json || true
   python3 tools/make_traffic.py --entry $O/pmc_sift1m.json:$O/pmc_sift1m_line.json${CLK:+:$CLK} --entry $O/pmc_sift1m_folded.json:$O/pmc_sift1m_folded_line.json \
       --entry $O/pmc_clusters.json:$O/pmc_clusters_line.json --entry $O/pmc_glove.json:$O/pmc_glove_line.json > $O/traffic.json
   cat $O/tests.txt; cat $O/bench.json

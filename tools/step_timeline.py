@@ -52,11 +52,21 @@ from nlsh_amd import io, synth  # noqa: E402
 from nlsh_amd.data import SIFT  # noqa: E402
 from nlsh_amd.indexer import Indexer  # noqa: E402
 
-N, d, Q = 1_000_000, 128, 10_000
-corpus_h, mean, std = synth.standardise(synth.sift_manifold(N, d, seed=synth.SEED_DATA))
-Ws, bs = io.load_hasher_weights(os.path.join(ROOT, "neural-locality-sensitive-hashing_amd", "checkpoints", "sift1m_manifold_h16.npz"))
-ix = Indexer(io.hashing_from_weights(Ws, bs, compat=True), torch.from_numpy(corpus_h).cuda(), SIFT.distance)
-qb = [torch.from_numpy(synth.standardise(synth.sift_manifold(Q, d, seed=synth.SEED_QUERY + 17 * i), mean, std)[0]).cuda() for i in range(4)]
+wl = os.environ.get("STEP_WORKLOAD", "sift1m")     # sift1m | clusters | glove (the environment, not argv: the tracer passes argv through)
+Q = 10_000
+ck = lambda n: os.path.join(ROOT, "neural-locality-sensitive-hashing_amd", "checkpoints", n)   # noqa: E731
+if wl == "glove":
+    from nlsh_amd.data import Glove
+    corpus_h = synth.glove_manifold(1_183_514, 100, seed=synth.SEED_DATA)
+    Ws, bs = io.load_hasher_weights(ck("glove_manifold_h24.npz"))
+    ix = Indexer(io.hashing_from_weights(Ws, bs, compat=False), torch.from_numpy(corpus_h).cuda(), Glove.distance, compat=False)
+    qb = [torch.from_numpy(synth.glove_manifold(Q, 100, seed=synth.SEED_QUERY + 17 * i)).cuda() for i in range(4)]
+else:
+    gen = synth.sift_like if wl == "clusters" else synth.sift_manifold
+    corpus_h, mean, std = synth.standardise(gen(1_000_000, 128, seed=synth.SEED_DATA))
+    Ws, bs = io.load_hasher_weights(ck("sift1m_clusters_h16.npz" if wl == "clusters" else "sift1m_manifold_h16.npz"))
+    ix = Indexer(io.hashing_from_weights(Ws, bs, compat=True), torch.from_numpy(corpus_h).cuda(), SIFT.distance)
+    qb = [torch.from_numpy(synth.standardise(gen(Q, 128, seed=synth.SEED_QUERY + 17 * i), mean, std)[0]).cuda() for i in range(4)]
 ix.query_tensors(qb[0], k=10, hash_times=10, seed=1)       # sizes the task table
 torch.cuda.synchronize()
 
