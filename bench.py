@@ -35,7 +35,7 @@ them, both on algorithmic quantities measured live: pair flops (3*d*sum(C_q), 2*
 vector peak, and the bytes of the batch's DISTINCT candidate rows against 8 TB/s; bound = "valu" unless the HBM fraction
 exceeds 1.5x the VALU fraction; both fractions are always printed, SURVEY 8(d)'s per-pair byte rate as
 `algorithmic_GBps`.  `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc pass of the SAME workload, schedule,
-row window and kernel sources (profiles/traffic_r05.json), else null.  `cpu_baseline` = the CPU restatements timed on this
+row window and kernel sources (profiles/traffic_r06.json), else null.  `cpu_baseline` = the CPU restatements timed on this
 box's host cores on a bounded sample.
 There is no dataset or reference checkpoint offline: data is seeded synthetic (`synth.sift_manifold`) and the hash is
 the one our minimal trainer learned on it (checkpoints/, see config.hash).
@@ -64,7 +64,7 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (155 TF measured)
 VALU_F32_PEAK_TFLOPS = 157.3  # same figure: 1024 SIMDs x 2.4 GHz x 64 lanes x 2 flop / 2 cycles per wave64 v_fma_f32
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_r05.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_r06.json")
 KERNEL_SOURCES = ("scan_bucket.hip", "scan_common.h", "scan_topk.hip", "common.h", "build_csr.hip")   # build_csr.hip: the cell packing shapes the scan's tasks
 
 

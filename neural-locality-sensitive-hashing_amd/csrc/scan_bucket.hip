@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void bscan2_kernel(BArgs a) {
     const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     long long ntasks = a.status[0];
     if (ntasks > a.max_tasks) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) a.status[1] = 1;  // incomplete: caller must retry
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&a.status[1], 1);  // incomplete: caller must retry (a refusal of the PLAN phase -- 2, 3 -- stays)
         ntasks = a.max_tasks;
     }
     if (t >= ntasks) return;
@@ -1285,7 +1285,7 @@ __global__ __launch_bounds__(64 * NW, NLSH_TILED_MIN_WAVES) void bscan3_kernel(B
     if (NLSH_PRIO_OUT >= 0) __builtin_amdgcn_s_setprio(NLSH_PRIO_OUT);
     long long ntasks = a.status[0];
     if (ntasks > a.max_tasks) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) a.status[1] = 1;  // incomplete: caller must retry
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&a.status[1], 1);  // incomplete: caller must retry (a refusal of the PLAN phase -- 2, 3 -- stays)
         ntasks = a.max_tasks;
     }
     // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Task ids are dealt to the XCDs

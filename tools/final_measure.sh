@@ -1,7 +1,9 @@
 # End-of-round measurement set (run on the GPU box from the repo root through gpurun; results under gpurun_out/final/, the ones
 # to be judged are copied to profiles/ afterwards).  Two calls (the Deep100M part needs the box to itself for a few minutes):
-#   bash tools/final_measure.sh main     # tests, bench lines, kernel statistics, counters of configs[1] (both generators, both L2 forms) and configs[2]
+#   bash tools/final_measure.sh lines    # tests, bench lines, shard-step profiles, host-enqueue probe, order / cache-flush experiment
+#   bash tools/final_measure.sh counters # kernel statistics, step timelines, counters of configs[1] (both generators, both L2 forms) and configs[2]
 #   bash tools/final_measure.sh deep     # configs[4] on one GPU: pipelined line, sequential line, counters of the sequential command
+#   (main = lines + counters in one call: longer than one gpurun call may last)
 # Needs lib/libnlsh_hip_trace.so for the clock pass:
 #   make -C neural-locality-sensitive-hashing_amd/csrc VARIANT=trace EXTRA="-DNLSH_SCAN_TRACE -DNLSH_SCAN_TRACE_CLOCK"
 set -e
@@ -15,7 +17,7 @@ pmc_bench() {   # $1 = tag, rest = bench.py flags: counters of the bench command
   (cd /tmp && TMPDIR=/tmp rocprofv3 --pmc $PMC --output-format csv -d /tmp/pm_$tag -- python3 $R/bench.py --no-cpu-baseline --no-side-workloads --steps 3 --warmup 1 --query-chunks 1 "$@" > $O/pmc_${tag}_line.json 2> /tmp/pm_$tag.err)
   python3 $R/tools/pmc_summary.py /tmp/pm_$tag > $O/pmc_$tag.json
 }
-if [ "${1:-main}" = "main" ]; then
+if [ "${1:-main}" = "main" ] || [ "$1" = "lines" ]; then
   python -m pytest tests -m gpu -q -x 2>&1 | tail -2 > $O/tests.txt
   python bench.py > $O/bench.json 2> $O/bench.err
   python bench.py --l2-form folded --no-cpu-baseline > $O/bench_folded.json 2>/dev/null
@@ -26,6 +28,9 @@ if [ "${1:-main}" = "main" ]; then
   for g in on off; do for w in 1 2 4 8; do python tools/shard_step_profile.py --world $w --rank 0 --steps 100 --pipeline --graph $g; done; done 2>/dev/null > $O/shard_step_profile_pipelined.jsonl
   python tools/graph_enqueue_probe.py 2>/dev/null > $O/graph_enqueue_probe.json
   for w in glove clusters sift1m; do python tools/order_alternation.py $w 2>/dev/null; done > $O/order_alternation_and_cache_flush.jsonl
+  cat $O/tests.txt; cat $O/bench.json
+fi
+if [ "${1:-main}" = "main" ] || [ "$1" = "counters" ]; then
   CLK=""
   if [ -f $R/neural-locality-sensitive-hashing_amd/lib/libnlsh_hip_trace.so ]; then
     NLSH_HIP_LIB=$R/neural-locality-sensitive-hashing_amd/lib/libnlsh_hip_trace.so python tools/scan_clock.py > $O/scan_clock.txt 2>/dev/null || true
@@ -56,8 +61,9 @@ if [ "${1:-main}" = "main" ]; then
   python3 $R/tools/pmc_summary.py /tmp/pm_ea bscan3 > $O/pmc_glove_ea_requests.json || true
   python3 tools/make_traffic.py --entry $O/pmc_sift1m.json:$O/pmc_sift1m_line.json${CLK:+:$CLK} --entry $O/pmc_sift1m_folded.json:$O/pmc_sift1m_folded_line.json \
       --entry $O/pmc_clusters.json:$O/pmc_clusters_line.json --entry $O/pmc_glove.json:$O/pmc_glove_line.json > $O/traffic.json
-  cat $O/tests.txt; cat $O/bench.json
-else
+  cat $O/step_timeline.txt
+fi
+if [ "$1" = "deep" ]; then
   CK=$R/neural-locality-sensitive-hashing_amd/checkpoints/deep100m_manifold_h32.npz
   python tools/scale_deep100m.py --load-hash $CK > $O/deep100m_pipelined.log 2>&1
   rm -rf /tmp/pm_deep
