@@ -19,8 +19,10 @@ The same hot path with results LEFT IN HBM (`query_tensors`: encode_hash -> plan
 pipeline that consumes device tensors sees) is timed in a second K-step region and reported as the top-level fields
 `device_resident_qps` / `device_resident_ms_per_step`; its scan kernel is bracketed by HIP events on the launch
 stream, which is where `roofline` comes from.  At N=1 the kernels of a device-resident step run back to back on one
-stream (each kernel alone on the chip); at N>1 they go through the three-stage pipeline of nlsh_amd/pipeline.py with
-the all-gather in its tail stage (`--pipeline on|off` forces either).
+stream (each kernel alone on the chip: ONE `nlsh_query_batch` call, five launches); at N>1 they go through the graph slots of
+nlsh_amd/pipeline.py with the all-gather behind each batch on its slot's stream (`--pipeline on|off` forces either), and the scan
+kernel is timed alone in a short sequential region of its own.  The default N=1 run also carries `workloads`: configs[2]
+(GloVe-1.2M-shaped) and configs[1] on SURVEY 8(d)'s own generator, 3 + 20 device-resident steps each (`--no-side-workloads` skips).
 N>1: corpus buckets sharded over the ranks (whole buckets per rank, one build-time all-to-all; `--shard rows` keeps
 contiguous row ranges), every rank answers all queries over its shard, one all-gather (RCCL) of the per-rank top-k +
 merge per step ("strong" scaling: total work fixed).
@@ -727,11 +729,11 @@ def main():
                                "the figure that scales is named by scaling_value_key"),
             "protocol_qps_opt_in": Q * steps / elapsed_opt_in,
             # the field of THIS line a scaling study should read: device-resident steps (results left in HBM, incl. the all-gather + merge at N>1);
-            # predicted ceiling from the one-GPU emulation of the per-rank pipelined local step (profiles/r05_shard_step_profile_step_api.jsonl:
-            # 0.295 / 0.170 / 0.116 / 0.090 ms at 1 / 2 / 4 / 8 bucket shards, host enqueue 0.055-0.066 ms per batch through the one-call
-            # step API): encode + PLAN + merge are replicated on every rank
+            # predicted ceiling from the one-GPU emulation of the per-rank pipelined local step (profiles/r06_shard_step_profile_pipelined.jsonl:
+            # 0.302 / 0.169 / 0.106 / 0.076 ms at 1 / 2 / 4 / 8 bucket shards, host enqueue 0.02 ms per batch through graph slots):
+            # encode + lookup, the task layout and the merge are replicated on every rank
             "scaling_value_key": "device_resident_qps",
-            "scaling_ceiling_note": "per-rank pipelined local step emulated on one GPU: x1.75 / x2.5 / x3.2 at N = 2 / 4 / 8 before the all-gather (replicated per-batch kernels; 18 HIP runtime calls per batch)",
+            "scaling_ceiling_note": "per-rank pipelined local step emulated on one GPU (graph slots, profiles/r06_shard_step_profile_pipelined.jsonl): 0.302 / 0.169 / 0.106 / 0.076 ms = x1.8 / x2.85 / x4.0 at N = 2 / 4 / 8 before the all-gather (the ~70 us of encode + lookup, task layout and merge every rank repeats; host enqueue 0.02 ms per batch)",
             "own_slice_qps": None if elapsed_own is None else Q * steps / elapsed_own,
             # N>1 only: the exchange as the data backend itself saw it (ranks counted by an all-reduce of ones, devices by an all-gather of PCI ids)
             "collective": collective,

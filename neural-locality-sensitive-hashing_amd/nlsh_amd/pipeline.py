@@ -1,26 +1,28 @@
-"""Three-stage software pipeline of query batches over three HIP streams.
+"""Software pipeline of query batches: slots that overlap consecutive batches on the device.
 
-A batch is `encode_hash` + the PLAN phase of the scan (bucket lookup, task table: five small latency-bound kernels),
-the SCAN phase (the scan kernel, which fills the chip), and the MERGE phase (per-query merge of the partial lists)
-followed, on a sharded index, by the all-gather + shard merge.  Run back to back on one stream, the first and the
-last group cost ~0.1 ms per batch during which most of the chip idles (and the collective's latency is exposed).
-Here the three groups of consecutive batches run on three streams:
+A batch is five launches (r06): `encode_hash` with the bucket lookup of the scan's PLAN phase in its epilogue, two small latency-bound
+kernels that lay out the (row segment, query group) tasks, the scan kernel, which fills the chip, and the per-query merge of the partial
+lists -- followed, on a sharded index, by the all-gather + shard merge.  Run back to back on one stream, everything but the scan costs
+~75 us per batch during which most of the chip idles (and the collective's latency is exposed).  Two kinds of slot overlap them:
 
-    front:  encode(i+1) plan(i+1)           | encode(i+2) plan(i+2) | ...
-    mid  :  scan(i)                         | scan(i+1)             | ...
-    tail :  merge(i-1) [all-gather(i-1)]    | merge(i) ...          | ...
+* graph slots (r06, the default for the bucket-major schedules; `nlsh_step_create_graph`, ABI v4): a slot owns a stream, the batch's five
+  launches are captured ONCE into a hipGraph, and `submit` replays it on that stream after the library has refreshed the two kernel
+  nodes that carry the batch pointer.  Batches of different slots overlap because their streams do; consecutive batches of one slot
+  are ordered by its stream.  Host cost per batch: one ctypes transition = one graph launch + two node updates + one event record
+  (0.02 ms; the staged slots' five launches + eight to ten event calls cost 0.05-0.10).  Two scan kernels may share the chip, so a scan
+  bracketed by events is not timed alone (a batch submitted WITH scan events is launched eagerly on the slot's stream instead);
+* staged slots (r03-r05, `graph=False`): the stages of consecutive batches on three (four) shared streams
 
-Scan kernels never overlap each other (they are all on the mid stream), so their HIP-event durations stay
-meaningful (they share the chip with the small kernels of the neighbouring batches: +7 %).  `depth` slots own the
-per-batch buffers (key table, task-table workspace, outputs); a slot is reused only after its tail stage has
-finished (event).  Results are bit-identical to `Indexer.query_tensors`: the kernels and their arguments are the
-same, only the stream they run on differs.  No reference counterpart (the reference answers one query at a time,
+      front:  encode(i+1) plan(i+1)           | encode(i+2) plan(i+2) | ...
+      mid  :  scan(i)                         | scan(i+1)             | ...
+      tail :  merge(i-1) [all-gather(i-1)]    | merge(i) ...          | ...
+
+  where scan kernels never overlap each other (their HIP-event durations stay meaningful: +7 %).
+
+`depth` slots own the per-batch buffers (key table, task-table workspace, outputs); a slot is reused only after its previous batch has
+finished (its own stream's order, or the tail event).  Results are bit-identical to `Indexer.query_tensors`: the kernels and their
+arguments are the same, only the stream they run on differs.  No reference counterpart (the reference answers one query at a time,
 nlsh/indexer.py:62-95).
-
-One C-ABI call per batch (r05, ABI v3): a slot is an `nlsh_step_t` of the library -- the validated encode launch, the scan call, the
-streams and the slot's events, built once -- and `submit` is ONE ctypes transition (`nlsh_query_step_enqueue`) that swaps in the batch
-pointer, its row stride and the Philox seed.  Through r04 `submit` issued the seven launches and ten event records / waits itself
-(~0.09 ms of host time per batch: at eight shards that WAS the step).
 
 Buffer lifetimes: a submitted batch is read by all stages after `submit` returns.  The pipeline keeps a reference to the batch tensor
 in the batch's slot, so the caller may drop it at once, but must not OVERWRITE it in place before `synchronize()` (or the batch's
