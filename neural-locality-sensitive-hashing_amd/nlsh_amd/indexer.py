@@ -641,16 +641,86 @@ class Indexer:
             self._perm_host = self.gid.cpu().numpy().astype(np.int64)
         return self._perm_host[span[0]:span[1]].tolist()
 
+    # `query()` launches the same row ranges of the same batch shape call after call, and everything it needs on the device is consumed
+    # before it returns (the results leave as Python lists).  So the range's buffers -- its slice of the batch's key table, distances,
+    # the id / count / status block -- and the descriptor of its `nlsh_query_batch` call are built ONCE per (batch shape, range, k,
+    # schedule) and kept: a later call checks that the task table, the workspace and the hasher's weights are still the ones the
+    # descriptor names and makes its one C call.  r06: the Python around that call (allocations, the descriptor's forty fields, the
+    # weight walk, argument tuples) was 0.08 ms per range = 0.2 ms of a 1.1-ms call (tools/query_host_profile.py).  `query_tensors`
+    # hands its tensors to the caller and keeps allocating fresh ones.  Like the scan workspace (one per stream), the kept buffers
+    # assume one `query()` at a time per indexer and stream.
+    def _range_plan(self, q, keys, nkeys, k, lo, hi, algo, hash_times, n_multi):
+        import ctypes
+        Q_all, P = keys.shape
+        dev, m = q.device, hi - lo
+        stream = _stream(dev)
+        ckey = (stream, Q_all, lo, hi, P, k, algo, self.l2_form, keys.data_ptr(), q.shape[1])
+        plans = self.__dict__.setdefault("_range_plans", {})
+        plan = plans.get(ckey)
+        tkey = self._tkey(algo, m, P)
+        window = self.choose_window(m, P, algo)
+        if tkey not in self._max_tasks:
+            grown = [v for (a_, q_, p_, w_), v in self._max_tasks.items() if a_ == algo and q_ >= m and p_ >= P and w_ == window]
+            self._max_tasks[tkey] = min(grown) if grown else self._estimate_tasks(m, P, self.seg_rows or 512, algo)
+        max_tasks = self._max_tasks[tkey]
+        wkey = (stream, True)
+        ws = self._ws.get(wkey)
+        sig = self._hashing._weights_signature()
+        if plan is not None and plan["max_tasks"] == max_tasks and plan["ws"] is ws and plan["window"] == window:
+            if plan["sig"] != sig:        # a training step between two calls: the descriptor gets the new blob
+                plan["packed"] = self._hashing.packed_weights()
+                plan["desc"].packed = plan["packed"].data_ptr()
+                plan["sig"] = sig
+            return plan
+        L, d = _capi.lib(), q.shape[1]
+        ws_bytes = L.nlsh_scan_workspace(m, P, k, max_tasks, self.n_buckets, d)
+        if ws is None or ws.numel() < ws_bytes or ws.device != dev:
+            ws = self._ws[wkey] = torch.zeros((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
+        rk, rn = keys[lo:hi], nkeys[lo:hi]
+        out_dist = torch.empty((m, k), dtype=torch.float32, device=dev)
+        pack = torch.empty((m * k + m + 2,), dtype=torch.int32, device=dev)
+        out_idx, ncand, status = pack[:m * k].view(m, k), pack[m * k:m * k + m], pack[m * k + m:]
+        (n_layers, dims_arr, packed_ptr, act, key_mode, n_probes), _ = self._hashing.encode_args(P, rk, rn)
+        pre, post = self._scan_args(m, d, rk, rn, k, algo, max_tasks, out_dist, out_idx, None, ncand, status, ws, window)
+        (corpus, row_stride, d_, gid, uniq, offsets, order, n_buckets, cell_of, cell_offsets, n_cells, inv_norm) = pre
+        (Q_, qkeys_p, nkeys_p, P_, k_, metric, algo_, seg, od, oi, ok, nc, st, wsp, wsb, mt) = post
+        desc = _capi.StepDesc(
+            n_layers=n_layers, act=act, key_mode=key_mode, n_probes=n_probes, dims=ctypes.cast(dims_arr, ctypes.c_void_p), packed=packed_ptr,
+            n_multi_rows=int(min(max(n_multi - lo, 0), m)), corpus_sorted=corpus, row_stride=row_stride, gid=gid, uniq_keys=uniq, offsets=offsets,
+            bucket_order=order, cell_of=cell_of, cell_offsets=cell_offsets, inv_norm=inv_norm, d=d_, n_buckets=n_buckets, n_cells=n_cells,
+            k=k_, metric=metric, algo=algo_, seg_rows=seg, hold_done=0, Q=Q_, qkeys=qkeys_p, nkeys=nkeys_p, out_dist=od, out_idx=oi,
+            out_keys=ok, out_ncand=nc, status=st, workspace=wsp, workspace_bytes=wsb, max_tasks=mt, front=None, plan=None, mid=None, tail=None)
+        plan = plans[ckey] = dict(desc=desc, ref=ctypes.byref(desc), size=ctypes.sizeof(desc), dims_arr=dims_arr, packed=self._hashing.packed_weights(), sig=sig,
+                                  keys=rk, nkeys=rn, out_dist=out_dist, pack=pack, status=status, ws=ws, wkey=wkey, max_tasks=max_tasks, tkey=tkey,
+                                  window=window, stream=stream, order_rotates=bool(self.alternate_order))
+        if len(plans) > 64:           # batch shapes come and go (a caller sweeping Q): keep the dictionary bounded
+            for old_key in list(plans)[:-32]:
+                del plans[old_key]
+        return plan
+
     def _range_tensors(self, q, keys, nkeys, k, lo, hi, algo, fused):
         """One row range of a `query()` batch on the stream: `fused` = (hash_times, seed, rows of the batch that are multi-probe) --
         the range is hashed AND scanned by one `nlsh_query_batch` call into its slice of the batch's key table; None: the table was
         filled by a whole-batch `hash_device` and the range is only scanned."""
         if fused is None:
             self.scan_tensors(q[lo:hi], keys[lo:hi], nkeys[lo:hi], k=k, check=False, algo=algo)
-        else:
-            hash_times, seed, n_multi = fused
+            return
+        hash_times, seed, n_multi = fused
+        if self.alternate_order:      # (experiment switch: the schedule order changes from call to call, so nothing is kept)
             self._batch_tensors(q[lo:hi], k, hash_times, seed, check=False, algo=algo, row0=lo, n_multi=min(max(n_multi - lo, 0), hi - lo),
                                 out=(keys[lo:hi], nkeys[lo:hi]))
+            return
+        plan = self._range_plan(q, keys, nkeys, k, lo, hi, algo, hash_times, n_multi)
+        qr = q[lo:hi]
+        try:
+            _capi.check(_capi.lib().nlsh_query_batch(plan["ref"], plan["size"], qr.data_ptr(), qr.stride(0), seed, lo, 0, None, None, plan["stream"]))
+        except _capi.NlshHipError:
+            self._ws.pop(plan["wkey"], None)    # a call that failed part-way may have left the counters at the head non-zero
+            self._range_plans.clear()
+            raise
+        self.last_status = plan["status"]
+        self.last_algo, self.last_window = algo, plan["window"]
+        self._last_pack, self._last_tkey, self._last_max_tasks = plan["pack"], plan["tkey"], plan["max_tasks"]
 
     def _host_results(self, q, keys, nkeys, k, fused=None):
         """Scan + device->host copies of (ids, candidate counts, status) and of the key table into pinned buffers + ONE
@@ -848,8 +918,13 @@ class Indexer:
         if self._fuses(q, hash_times, self.choose_algo(Q, hash_times)):
             # every row range is hashed and scanned by ONE call (five launches); the ranges share the batch's key table, seed and the
             # Philox counters of its rows, so the split changes no key
-            keys = torch.empty((Q, hash_times), dtype=torch.int32, device=q.device)
-            nkeys = torch.empty((Q,), dtype=torch.int32, device=q.device)
+            tab = self.__dict__.setdefault("_key_tables", {})
+            tkey_ = (q.device, Q, hash_times)
+            if tkey_ not in tab:          # the batch's key table is consumed inside the call (pinned copy for the F7 rule): kept per batch shape
+                if len(tab) > 8:
+                    tab.clear()
+                tab[tkey_] = (torch.empty((Q, hash_times), dtype=torch.int32, device=q.device), torch.empty((Q,), dtype=torch.int32, device=q.device))
+            keys, nkeys = tab[tkey_]
             fused = (hash_times, self._hashing.next_seed() if seed is None else seed, self._n_multi_rows(Q))
         else:
             keys, nkeys = self.hash_device(q, hash_times=hash_times, seed=seed)

@@ -447,3 +447,39 @@ def test_train_hash_tool_on_a_texmex_directory(tmp_path):
     assert 0.0 <= last["test/recall"] <= 1.0 and last["test/query_size"] > 0          # the reference's metric names (base.py:105-108)
     Ws, bs = io.load_hasher_weights(str(out_path))
     assert [w.shape for w in Ws] == [(256, d), (256, 256), (8, 256)] and all(b is not None for b in bs)
+
+
+def test_query_keeps_its_range_plans_and_follows_weight_updates_and_table_growth():
+    """r06: `Indexer.query` builds the buffers and the `nlsh_query_batch` descriptor of each row range once per batch shape and reuses
+    them call after call.  The kept descriptor must follow what can change underneath it: the hasher's weights (a training step between
+    two validation calls, nlsh/trainers/base.py:80-96), the task table (grown after an overflow, trimmed after the first call) and the
+    batch shape -- every call equals the lists derived from a `query_tensors` call on the same seed, which builds everything afresh."""
+    from nlsh_amd.data import SIFT
+    from nlsh_amd.indexer import Indexer
+    N, d, H, k, P = 30000, 128, 12, 10, 10
+    corpus, mean, std = synth.standardise(synth.sift_like(N, d, seed=191))
+    Ws, bs = synth.make_weights([d, 64, H], seed=193)
+    hashing = make_hashing(d, [64], H, Ws, bs, compat=False, seed=5)
+    ix = Indexer(hashing, dev(corpus), SIFT.distance, compat=False)
+    ix.query_chunks, ix._CHUNK_MIN_ROWS = 2, 1024
+
+    def fresh(q, seed):
+        _, idx, nc, _ = ix.query_tensors(q, k=k, hash_times=P, seed=seed)
+        return [[int(v) for v in row if v >= 0] for row in idx.cpu().numpy()], nc.cpu().tolist()
+
+    qa = dev(synth.standardise(synth.sift_like(4500, d, seed=192), mean, std)[0])
+    qb = dev(synth.standardise(synth.sift_like(3000, d, seed=194), mean, std)[0])
+    for step, q in enumerate((qa, qa, qb, qa)):
+        want = fresh(q, 700 + step)
+        assert ix.query(q, k=k, hash_times=P, seed=700 + step) == tuple(want) or list(ix.query(q, k=k, hash_times=P, seed=700 + step)) == list(want)
+    plans_before = len(ix._range_plans)
+    assert plans_before >= 3                                  # two ranges of the 4500-row shape, two of the 3000-row one; none rebuilt per call
+    with torch.no_grad():                                     # "a training step": new weights, same tensors
+        for prm in hashing.parameters():
+            prm.mul_(-0.5)
+    want = fresh(qa, 900)
+    got = ix.query(qa, k=k, hash_times=P, seed=900)
+    assert list(got) == list(want) and len(ix._range_plans) == plans_before
+    ix._max_tasks = {key: 64 for key in ix._max_tasks}        # every kept descriptor now names a table that is too small
+    got = ix.query(qa, k=k, hash_times=P, seed=901)
+    assert list(got) == list(fresh(qa, 901)) and min(ix._max_tasks[key] for key in ix._max_tasks if key[1] in (2250,)) > 64

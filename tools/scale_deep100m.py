@@ -175,10 +175,15 @@ def main():
     step(-1)
     drain()
     t0 = time.perf_counter()
+    graph_slots = pipe is not None and getattr(pipe, "graph", False)
     for i in range(args.steps):
-        out = step(i, events=ev[i])
+        out = step(i, events=None if graph_slots else ev[i])    # graph slots replay a batch only without scan events, and overlap whole batches
     drain()
     elapsed = time.perf_counter() - t0
+    if graph_slots:    # the scan kernel alone on the chip: a sequential region of its own (same batch, same seed), outside the timed one
+        for i in range(args.steps):
+            indexer.query_tensors(queries, k=k, hash_times=P, seed=1, want_keys=world > 1, check=False, events=ev[i])
+        drain()
     if pipe is not None:
         assert not pipe.overflowed()
     else:
@@ -233,7 +238,7 @@ def main():
             "corpus_gb": N * d * 4 / 1e9, "generate_s": gen_s, "train_s": train_s, "index_build_s": build_s,
             "rank0_rows": int(indexer._candidate_vectors_gpu.shape[0]), "rank0_buckets": stats["n_indexes"], "bucket_mean": stats["mean"],
             "bucket_max": stats["max"], "queries_per_s": Q * args.steps / elapsed, "ms_per_step": 1e3 * elapsed / args.steps,
-            "step_driver": "three-stage pipeline" if pipe is not None else "sequential: every kernel of a step back to back on one stream",
+            "step_driver": ("graph slots: every batch one captured hipGraph on its slot's own stream" if graph_slots else "three-stage pipeline") if pipe is not None else "sequential: every kernel of a step back to back on one stream",
             "scan_kernel": {0: "query-major", 1: "bucket-major", 2: "bucket-major LDS-tiled"}[algo],
             "rank0_scan_ms": scan_ms, "mean_candidates_per_query": sum_c / Q,
             "rank0_algorithmic_GBps": 4.0 * d * sum_c_local / (scan_ms * 1e-3) / 1e9,
@@ -257,7 +262,9 @@ def main():
                 "l2_form": args.l2_form, "window_rows": int(indexer.last_window),
                 "note": ("scan kernel timed with HIP events in a SEQUENTIAL region: every kernel of a step back to back on one stream, the scan alone on the chip"
                          if pipe is None else
-                         "scan kernel timed with HIP events inside the three-stage pipeline (shares the chip with the neighbouring batches' small kernels)")},
+                         ("queries/s through graph slots; the scan kernel timed with HIP events in a sequential region of its own after the timed one (two batches' scans may share the chip inside it)"
+                          if graph_slots else
+                          "scan kernel timed with HIP events inside the three-stage pipeline (shares the chip with the neighbouring batches' small kernels)"))},
             "recall_at_10_on_sample": recall, "recall_sample": R, "properties": "ascending, distances vs torch on regenerated rows: ok",
             "rank0_peak_mem_gb": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
     if world > 1:
