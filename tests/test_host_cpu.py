@@ -471,6 +471,35 @@ def test_step_create_refuses_equal_streams_and_bad_scan_arguments_before_anythin
     assert L.nlsh_step_create_graph(ctypes.byref(d_), ctypes.sizeof(d_), None, ctypes.byref(handle)) == _capi.E_INVALID
 
 
+def test_query_batch_argument_errors_are_reported_before_any_launch():
+    """`nlsh_query_batch` (ABI v4): a descriptor of another size (a binding built against another header), a missing batch pointer, an
+    encoder whose input width is not the corpus dimension and a probe count beyond one scan call are refused on the host; an empty batch
+    is a no-op.  None of these paths touches the device, so they are checked here."""
+    import ctypes
+    from nlsh_amd import _capi
+    L = _capi.lib()
+    dims = _capi.int_array([128, 64, 16])
+    buf = (ctypes.c_char * 4096)()
+    a = ctypes.addressof(buf)
+    def desc(**kw):
+        base = dict(n_layers=2, act=0, key_mode=0, n_probes=10, dims=ctypes.cast(dims, ctypes.c_void_p), packed=a, n_multi_rows=0,
+                    corpus_sorted=a, row_stride=128, gid=a, uniq_keys=a, offsets=a, bucket_order=a, cell_of=None, cell_offsets=None, inv_norm=None,
+                    d=128, n_buckets=8, n_cells=0, k=10, metric=0, algo=2, seg_rows=0, hold_done=0, Q=64, qkeys=a, nkeys=a, out_dist=a, out_idx=a,
+                    out_keys=None, out_ncand=a, status=a, workspace=a, workspace_bytes=4096, max_tasks=16, front=None, plan=None, mid=None, tail=None)
+        base.update(kw)
+        return _capi.StepDesc(**base)
+    d_ = desc()
+    assert L.nlsh_query_batch(ctypes.byref(d_), ctypes.sizeof(d_) - 8, a, 128, 1, 0, 0, None, None, None) == _capi.E_INVALID
+    assert b"descriptor" in L.nlsh_last_error()
+    assert L.nlsh_query_batch(ctypes.byref(d_), ctypes.sizeof(d_), None, 128, 1, 0, 0, None, None, None) == _capi.E_INVALID
+    d0 = desc(Q=0)
+    assert L.nlsh_query_batch(ctypes.byref(d0), ctypes.sizeof(d0), None, 128, 1, 0, 0, None, None, None) == _capi.OK      # empty batch: nothing to do
+    dd = desc(d=96)
+    assert L.nlsh_query_batch(ctypes.byref(dd), ctypes.sizeof(dd), a, 128, 1, 0, 0, None, None, None) == _capi.E_INVALID
+    dp = desc(n_probes=65)
+    assert L.nlsh_query_batch(ctypes.byref(dp), ctypes.sizeof(dp), a, 128, 1, 0, 0, None, None, None) == _capi.E_UNSUPPORTED
+
+
 def test_fastlists_builds_the_same_lists_as_ndarray_tolist():
     """csrc/fastlists.c: the host-side list builder of `Indexer._plain_lists` is `ndarray.tolist()` element for element (types too),
     refuses a short buffer, and is what the facade uses when it is built."""
