@@ -173,3 +173,36 @@ def test_folded_l2_form_differs_from_exact_only_at_ties_on_all_queries(sift1m):
     r1 = calculate_recall(list(gt), [r[r >= 0].tolist() for r in i1.cpu().numpy()], np.mean)
     assert abs(r0 - r1) <= n_diff / (10.0 * len(gt)) + 1e-12, (r0, r1)    # recall can move by at most the ids those ties substituted
     print(f"[l2 forms, SIFT1M] id lists differing: {n_diff} of {len(gt)}; recall@10 exact {r0:.6f} folded {r1:.6f}")
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_pipeline_slots_stay_exact_when_the_host_runs_ahead_of_the_device(sift1m, graph):
+    """r06: a graph slot refreshes two kernel nodes of its captured graph (batch pointer, seed) and launches it again while -- at full
+    size the device is the slower side -- the slot's PREVIOUS launch of the same executable graph may still be running.  The update must
+    only reach the launches that follow it: 24 different batches through two slots with no synchronisation in between, every batch's
+    results copied out on its slot's stream right behind it, all compared bit for bit with sequential calls.  (Same check for the staged
+    slots, whose events order the stages.)"""
+    from nlsh_amd.pipeline import QueryPipeline
+    ix = sift1m["indexers"]["tiled"]
+    qg, k, P, nb = sift1m["qg"], 10, 10, 24
+    batches = [torch.roll(qg, shifts=37 * i + 1, dims=0).contiguous() for i in range(nb)]      # 24 different batches of the headline's shape
+    want = []
+    for i, b in enumerate(batches):
+        d_, i_, n_, _ = ix.query_tensors(b, k=k, hash_times=P, seed=300 + i, check=True)
+        want.append((d_.clone(), i_.clone(), n_.clone()))
+    pipe = QueryPipeline(ix, batches[0], k=k, hash_times=P, depth=2, graph=graph)
+    assert pipe.graph == graph
+    torch.cuda.synchronize()
+    got = []
+    for i, b in enumerate(batches):
+        out = pipe.submit(b, seed=300 + i)
+        stream = pipe.last_slot.lane if graph else pipe.tail
+        with torch.cuda.stream(stream):                      # behind the batch on the stream it ends on, before the slot is reused
+            got.append(tuple(t.clone() for t in out[:3]))
+    pipe.synchronize()
+    torch.cuda.synchronize()
+    assert not pipe.overflowed()
+    for i in range(nb):
+        for a, w in zip(got[i], want[i]):
+            assert torch.equal(a, w), (graph, i)
+    pipe.close()
