@@ -289,7 +289,9 @@ int nlsh_step_create(const nlsh_step_desc_t *desc, size_t desc_bytes, nlsh_step_
  * two kernel-node updates (the batch pointer / row stride / seed of the encode, the query pointer of the scan) and one event record --
  * a third of the runtime calls of a staged slot.  Batches of different slots overlap because their lanes do; consecutive batches of one
  * slot are ordered by its lane.  hold_done: the caller's extra work goes on `lane`.  A call with scan events is launched eagerly on the
- * lane (same kernels).  Bucket-major schedules only (algo 1, 2).  Same results as the staged slots and the separate calls, bit for bit. */
+ * lane (same kernels), and so is every batch of a slot whose capture or instantiation the runtime refused (or NLSH_STEP_NO_GRAPH set in the
+ * environment when the slot is created: diagnostic).  Bucket-major schedules only (algo 1, 2).  Same results as the staged slots and the
+ * separate calls, bit for bit. */
 int nlsh_step_create_graph(const nlsh_step_desc_t *desc, size_t desc_bytes, nlsh_stream_t lane, nlsh_step_t **step_out);
 int nlsh_step_destroy(nlsh_step_t *step);
 /* New packed weights (nlsh_encoder_pack) for the batches enqueued from now on (a training step between two batches). */

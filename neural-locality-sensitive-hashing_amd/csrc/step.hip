@@ -13,6 +13,7 @@
 // r06 (ABI v4): the batch is FIVE launches -- the bucket lookup of the PLAN phase runs in encode_hash's epilogue (scan_plan.h) whenever
 // the schedule is a bucket-major one, and the rest of the PLAN phase is two launches instead of three -- and the same batch exists
 // as a one-stream call for callers that do not pipeline (nlsh_query_batch: what `Indexer.query_tensors` issues).
+#include <cstdlib>
 #include <new>
 
 #include "step_nodes.h"
@@ -30,6 +31,7 @@ struct nlsh_step {
     hipGraph_t graph;
     hipGraphExec_t exec;
     hipGraphNode_t enc_node, scan_node;
+    bool graph_failed;   // the capture or the instantiation did not work on this runtime: the slot launches its batches eagerly on its stream
 };
 
 // One batch's scan call as the bucket-major descriptor (validated), or -- query-major schedule -- nothing (fused = false).
@@ -89,6 +91,7 @@ static int step_create(const nlsh_step_desc_t *desc, size_t desc_bytes, hipStrea
     s->ready = s->encoded = s->planned = s->scanned = s->done = nullptr;
     s->done_pending = false;
     s->lane = lane; s->graph = nullptr; s->exec = nullptr; s->enc_node = s->scan_node = nullptr;
+    s->graph_failed = getenv("NLSH_STEP_NO_GRAPH") != nullptr;    // diagnostic: a graph slot without its graph (what a failed capture leaves)
     const hipStream_t last = lane ? lane : (hipStream_t)desc->tail;    // the stream a batch ends on
     int rc = encode_plan_fill(s->enc, desc->Q, desc->n_layers, s->dims, desc->packed, desc->act, desc->key_mode, desc->n_probes, desc->n_multi_rows, 0,
                               nullptr, nullptr, nullptr, desc->qkeys, desc->nkeys);
@@ -214,16 +217,23 @@ static int graph_enqueue(nlsh_step *s, const float *queries, int64_t q_stride, u
         }
     }
     int rc;
-    if (ev0 || ev1) {
+    if (!s->exec && !s->graph_failed && !(ev0 || ev1)) {
+        // Captured once.  A runtime that cannot capture or instantiate the batch (nothing has been launched by a failed capture) leaves the
+        // slot what a graph slot is without its graph: the same five launches, eagerly, on the slot's own stream -- same results, same
+        // overlap between slots, ~0.005 ms more host time per batch (profiles/r06_shard_step_profile_eager_on_lane_vs_staged.jsonl).
+        if (graph_capture(s, queries, q_stride, seed) != NLSH_OK) {
+            s->graph_failed = true;
+            if (s->exec) { (void)hipGraphExecDestroy(s->exec); s->exec = nullptr; }
+            if (s->graph) { (void)hipGraphDestroy(s->graph); s->graph = nullptr; }
+            (void)hipGetLastError();
+        }
+    }
+    if (ev0 || ev1 || !s->exec) {
         int plan_phase, plan_blocks;
         rc = launch_encode(s->enc, s->d, queries, q_stride, seed, lane, &plan_phase, &plan_blocks);
         if (rc == NLSH_OK) rc = scan_call(s->d, queries, q_stride, ev0, ev1, (nlsh_stream_t)lane, plan_phase | NLSH_PHASE_SCAN | NLSH_PHASE_MERGE, plan_blocks, nullptr);
         if (rc != NLSH_OK) return rc;
     } else {
-        if (!s->exec) {
-            rc = graph_capture(s, queries, q_stride, seed);
-            if (rc != NLSH_OK) return rc;
-        }
         // this batch's arguments of the two nodes that carry them
         BucketScanCall c;
         rc = scan_call(s->d, queries, q_stride, nullptr, nullptr, (nlsh_stream_t)lane, NLSH_PHASE_SCAN, 0, &c);

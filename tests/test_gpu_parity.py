@@ -521,7 +521,12 @@ def test_pipelined_batches_are_bit_identical_to_sequential_calls():
         batches = [dev(gen(Q, d, seed=50 + i)) for i in range(5)]
         want = [indexer.query_tensors(b, k=k, hash_times=P, seed=900 + i, want_keys=True) for i, b in enumerate(batches)]
         want = [tuple(t.clone() for t in w) for w in want]
-        for depth, graph in ((2, False), (3, False), (2, True), (3, True)):    # staged streams (r03-r05) and graph slots (r06), either depth
+        for depth, graph in ((2, False), (3, False), (2, True), (3, True), (3, "no-graph")):    # staged streams (r03-r05), graph slots (r06), and a graph slot whose capture failed
+            if graph == "no-graph":
+                os.environ["NLSH_STEP_NO_GRAPH"] = "1"      # read by nlsh_step_create_graph: the slot launches eagerly on its own stream
+                graph = True
+            else:
+                os.environ.pop("NLSH_STEP_NO_GRAPH", None)
             pipe = QueryPipeline(indexer, batches[0], k=k, hash_times=P, depth=depth, want_keys=True, graph=graph)
             assert pipe.graph == (graph and algo != "query")      # graph slots exist for the bucket-major schedules
             got = []
@@ -534,6 +539,7 @@ def test_pipelined_batches_are_bit_identical_to_sequential_calls():
                             assert torch.equal(a, w), (metric, algo, depth, graph, j)
             assert not pipe.overflowed()
             pipe.close()
+        os.environ.pop("NLSH_STEP_NO_GRAPH", None)
 
 
 @pytest.mark.parametrize("metric,d,algo", [("l2", 128, "tiled"), ("cosine", 100, "tiled"), ("l2", 72, "tiled"), ("l2", 128, "bucket"), ("cosine", 100, "bucket")])
