@@ -187,7 +187,7 @@ def traffic_entry(key, shape, learned):
             w = ent["workload"]
             if (w["N"], w["d"], w["Q"], w["H"], w["hash_times"], w["algo"], w["window_rows"]) == tuple(shape):
                 src = "profiles/" + os.path.basename(TRAFFIC_FILE) + " (rocprofv3 --pmc on the profile box, same workload, schedule and kernel sources; not this run)"
-                return ent["traffic_bytes_per_launch"], ent.get("valu_wave_instructions_per_launch"), ent.get("clock_held_GHz"), src, ent.get("dram_bytes_per_launch")
+                return ent["traffic_bytes_per_launch"], ent.get("valu_wave_instructions_per_launch"), ent.get("clock_held_GHz"), src, ent.get("origin")
     except (OSError, KeyError, ValueError, TypeError):
         pass
     return None, None, None, None, None
@@ -285,8 +285,8 @@ def side_workload(tag, args, dev, steps=20, warmup=3):
     roof = bucket_major_roofline(kernel, metric, d, sum_c, uniq_rows, scan_ms * 1e-3)
     traffic, _, _, src, dram = traffic_entry(f"{w['workload']}:{w['data']}:exact", (N, d, Q, H, P, algo, int(indexer.last_window)), True)
     roof.update({"traffic": traffic, "traffic_source": src, "avg_launch_ms": scan_ms, "tasks_per_launch": n_tasks})
-    if dram is not None:
-        roof["dram_bytes_per_launch"] = dram
+    if dram is not None:      # DRAM vs Infinity Cache, as far as the pool's counters go (profiles/traffic_r06.json: `origin`)
+        roof["traffic_origin"] = dram
     gt = brute_force_topk(qb[0], corpus, k, metric).cpu().numpy()
     ids0, nc0 = indexer.query(qb[0], k=k, hash_times=P, seed=5000)
     stats = indexer.bucket_stats()
@@ -704,8 +704,8 @@ def main():
                      "algorithmic_flops_per_launch": algo_flops, "sum_candidates_per_launch": sum_c_local, "tasks_per_launch": n_tasks})
         if traffic:
             roof["hbm_frac_of_measured_traffic"] = traffic / t_scan / 1e9 / HBM_PEAK_GBPS
-        if dram_bytes is not None:
-            roof["dram_bytes_per_launch"] = dram_bytes
+        if dram_bytes is not None:     # where the bytes come from, as far as the pool's counters go (profiles/traffic_r06.json: `origin`)
+            roof["traffic_origin"] = dram_bytes
         if valu_insts:
             roof["valu_wave_instructions_per_launch"] = valu_insts
             roof["valu_issue_frac"] = valu_insts * 2.0 / (1024 * t_scan * 2.4e9)

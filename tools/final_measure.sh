@@ -60,7 +60,8 @@ if [ "${1:-main}" = "main" ] || [ "$1" = "counters" ]; then
   rm -rf /tmp/pm_ea && (cd /tmp && TMPDIR=/tmp rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d /tmp/pm_ea -- python3 $R/bench.py --no-cpu-baseline --no-side-workloads --steps 3 --warmup 1 --query-chunks 1 --workload glove > /dev/null 2> /tmp/pm_ea.err) || true
   python3 $R/tools/pmc_summary.py /tmp/pm_ea bscan3 > $O/pmc_glove_ea_requests.json || true
   python3 tools/make_traffic.py --entry $O/pmc_sift1m.json:$O/pmc_sift1m_line.json${CLK:+:$CLK} --entry $O/pmc_sift1m_folded.json:$O/pmc_sift1m_folded_line.json \
-      --entry $O/pmc_clusters.json:$O/pmc_clusters_line.json --entry $O/pmc_glove.json:$O/pmc_glove_line.json > $O/traffic.json
+      --entry $O/pmc_clusters.json:$O/pmc_clusters_line.json --entry $O/pmc_glove.json:$O/pmc_glove_line.json \
+      $( [ -f $O/order_alternation_and_cache_flush.jsonl ] && echo --origin glove:manifold:exact:$O/pmc_glove_ea_requests.json:$O/order_alternation_and_cache_flush.jsonl ) > $O/traffic.json
   cat $O/step_timeline.txt
 fi
 if [ "$1" = "deep" ]; then

@@ -21,6 +21,10 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--entry", action="append", required=True)
+    ap.add_argument("--origin", action="append", default=[], metavar="TRAFFIC_KEY:EA_REQUESTS.json:FLUSH_EXPERIMENT.jsonl",
+                    help="r06 (VERDICT r05 item 3): where an entry's bytes come from, as far as this pool can tell -- the fabric-side read requests of the launch "
+                         "(TCC_EA0_RDREQ / _DRAM / _32B via tools/pmc_summary.py) and the same launch with the Infinity Cache flushed between batches "
+                         "(tools/order_alternation.py); there is no counter behind the fabric, so `dram_bytes_per_launch` itself stays null")
     ap.add_argument("--method", default="rocprofv3 --pmc FETCH_SIZE SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU -- "
                                          "python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 --query-chunks 1 [workload flags] (tools/final_measure.sh); per-launch average "
                                          "of the scan kernel (tools/pmc_summary.py); bytes = FETCH_SIZE(KB) * 1024 * 2")
@@ -43,6 +47,21 @@ def main():
             ent["clock_held_GHz"] = float(parts[2])
             ent["note_clock"] = "in-kernel shader clock of the tiled kernel on this workload (tools/scan_clock.py on a -DNLSH_SCAN_TRACE -DNLSH_SCAN_TRACE_CLOCK build), median over workgroups longer than 20 us"
         out["entries"][line["config"]["traffic_key"]] = ent
+    for spec in args.origin:
+        key, ea_file, flush_file = spec.rsplit(":", 2)      # the traffic key itself holds colons
+        ea = json.load(open(ea_file))
+        ea = ea[next(iter(ea))]
+        wl = {"glove:manifold:exact": "glove", "sift1m:clusters:exact": "clusters", "sift1m:manifold:exact": "sift1m"}[key]
+        fl = next(json.loads(ln) for ln in open(flush_file) if ln.startswith("{") and json.loads(ln).get("workload") == wl)
+        out["entries"][key]["origin"] = {
+            "dram_bytes_per_launch": None,
+            "why_null": "rocprofv3 --list-avail on this pool has no counter behind the fabric (no UMC / DF / MALL block): Infinity-Cache hits cannot be told from DRAM reads",
+            "fabric_read_requests_per_launch": ea.get("TCC_EA0_RDREQ_sum"), "of_which_routed_to_local_dram": ea.get("TCC_EA0_RDREQ_DRAM_sum"),
+            "of_which_32_byte": ea.get("TCC_EA0_RDREQ_32B_sum"),
+            "scan_ms_same_order_every_batch": [fl["same_order_0"][0], fl["same_order_1"][0]],
+            "scan_ms_infinity_cache_flushed_between_batches": fl["same_order_cache_flushed_between_batches"][0],
+            "reading": "routing, not residency: every read request of the launch goes towards local DRAM; with a 512-MiB write between batches (nothing of the previous batch left on "
+                       "the die) the same launch is this much slower, i.e. consecutive batches already get a large share of their rows from the Infinity Cache"}
     print(json.dumps(out, indent=1))
 
 
